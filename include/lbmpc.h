@@ -1,0 +1,247 @@
+/*
+ * lbmpc.h -- C ABI of liblbmpc_hip.so: the MI355X (gfx950) data-parallel core of learning-based
+ * rigid-tube MPC, a drop-in for the MATLAB entry points of gabormarko/learning-based-mpc.
+ *
+ * The reference has no FFI of its own (it is MATLAB calling MPT3 / YALMIP / CasADi+IPOPT); the
+ * boundary kept is the MATLAB signatures.  Each entry point below cites the
+ * reference code it replaces (paths relative to the reference root).  A MEX gateway
+ * (learning-based-mpc_amd/matlab/lbmpc_mex.cpp) and the ctypes mirror
+ * (learning-based-mpc_amd/lbmpc/) bind exactly these symbols.
+ *
+ * Conventions
+ *   - all reals are IEEE fp64; all matrices are COLUMN-MAJOR (MATLAB layout), leading dim = rows.
+ *   - "host" entry points take host pointers and copy in/out; "_dev" entry points take device
+ *     pointers for the bulk operands (samples, directions, outputs) and a hipStream_t (as void*),
+ *     enqueue asynchronously and do not synchronise.  Small constant operands (A, W_A, ...) are
+ *     always host pointers.
+ *   - return value: 0 ok; <0 usage error (LBMPC_ERR_*); >0 numerical status (LBMPC_ST_*).
+ *     No exceptions cross the ABI.  The reference has no status at all (IPOPT fails silently,
+ *     Functions_general/UQRobustMPC.m:156-158).
+ *   - every entry point needs a gfx950 device; there is no CPU fallback.
+ */
+#ifndef LBMPC_H
+#define LBMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LBMPC_VERSION 100 /* 0.1.0 */
+
+/* usage errors */
+#define LBMPC_ERR_ARG (-1)         /* null pointer / negative size / inconsistent dims      */
+#define LBMPC_ERR_DIM (-2)         /* dimension beyond the compiled limits below            */
+#define LBMPC_ERR_HIP (-3)         /* a HIP runtime call failed (see lbmpc_last_error)      */
+#define LBMPC_ERR_UNSUPPORTED (-4) /* e.g. prior W that is not an axis-aligned box          */
+#define LBMPC_ERR_NODEVICE (-5)    /* no gfx950 device visible                              */
+
+/* numerical statuses (also the per-trial / per-problem status words) */
+#define LBMPC_ST_OK 0
+#define LBMPC_ST_QP_INFEASIBLE 1 /* tube QP has no feasible point                          */
+#define LBMPC_ST_LP_INFEASIBLE 2 /* a sample lies outside the prior W (beta < 0 needed)    */
+#define LBMPC_ST_ITER_CAP 3      /* active-set iteration cap reached                       */
+#define LBMPC_ST_SAMPLER_CAP 4   /* rejection sampler hit max attempts                     */
+
+/* compiled limits */
+#define LBMPC_MAX_NX 4
+#define LBMPC_MAX_NZ 16 /* nx + N*nu */
+#define LBMPC_MAX_NC 16
+#define LBMPC_MAX_NW 16
+#define LBMPC_MAX_NXI 32 /* rows of Xi_true_EV / Xi_true_LV H-rep */
+#define LBMPC_MAX_NV 1024 /* vertices of the V-rep in the support sweep; also s*nV <= 2048 */
+#define LBMPC_MAX_S 64   /* terms of the Minkowski sum            */
+
+int lbmpc_version(void);
+/* Select device `device`, check it is gfx950. Must be called once per process before anything else. */
+int lbmpc_init(int device);
+/* Text of the last HIP/usage error on this thread (static storage). */
+const char* lbmpc_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Subsystem 1: support functions for the mRPI set / tube tightening
+ * ---------------------------------------------------------------------------------------- */
+
+/* h_out[i] = (1-alpha)^-1 * sum_{t=0}^{s-1} h_W(P_t d_i),  h_W(p) = max_v Vw[v,:].p,
+ * P_t = (A^t)' if transpose_flag else A^t.  D is nx x nd (one direction per column).
+ * s=1, alpha=0 gives plain h_W(d).
+ * Replaces: MPT3 `W.support(dirs)` as used by Functions_general/MRPISet.m:29,45 and the
+ * support LPs of Functions_general/UQRobustMPC.m:109-122 (Com_hs) /
+ * Functions_general/ComputeFeasibleRegion.m:447-503, for S = (1-alpha)^-1 (+)_{t<s} A^t W. */
+int lbmpc_support_batch(const double* A, int nx, const double* Vw, int nV, int s, double alpha,
+                        const double* D, int64_t nd, int transpose_flag, double* h_out);
+int lbmpc_support_batch_dev(const double* A, int nx, const double* Vw, int nV, int s, double alpha,
+                            const double* D_dev, int64_t nd, int transpose_flag, double* h_out_dev,
+                            void* stream);
+
+/* The (s, alpha) search of Functions_general/MRPISet.m:27-63 (mode 0: Ms = max over t=1..s and
+ * d in Dirs of h_W(A^t d)), of Functions/MRPISet.m:8-17 (mode 1: Ms = max_d sum_{t=1..s}
+ * h_W(A^t d)), or the exact Rakovic form (mode 2: alpha = max_j h_W((A^s)' f_j)/g_j,
+ * Ms = max_d sum_{t=0}^{s-1} h_W((A^t)' d)).  Dirs is nx x ndirs (column = direction), WA is
+ * nW x nx, Wb nW.  Loop: s = 0; while alpha > eps/(eps+Ms): s++ ... (both start at 1000). */
+#define LBMPC_MS_MAX_LITERAL 0
+#define LBMPC_MS_SUM_LITERAL 1
+#define LBMPC_MS_RAKOVIC 2
+int lbmpc_mrpi_s_alpha(const double* A, int nx, const double* Vw, int nV, const double* WA,
+                       const double* Wb, int nW, const double* Dirs, int ndirs, double eps, int mode,
+                       int max_s, int* s_out, double* alpha_out, double* Ms_out);
+
+/* ------------------------------------------------------------------------------------------
+ * Subsystem 2: homothetic disturbance-set learning over the information set I_0^w
+ * ---------------------------------------------------------------------------------------- */
+
+/* m_out[j + nW*b] = max_i WA[j,:] . samples[:, i] over the N samples of information set b.
+ * samples: `batch` blocks, block b starts at samples + b*batch_stride (in doubles), each block
+ * is nx x N column-major (one sample per column).  N >= 1.
+ * Replaces: the nW*N `W_A*(w_i - y) <= (1-beta) W_b` constraint rows of
+ * Functions_general/InitialSetComputation.m:77-79 / :93-95 (they enter the LP only through
+ * this maximum) and the sample row of Functions_general/UQRobustMPC.m:135. */
+int lbmpc_halfspace_max(const double* WA, int nW, int nx, const double* samples, int64_t N,
+                        int64_t batch, int64_t batch_stride, double* m_out);
+int lbmpc_halfspace_max_dev(const double* WA, int nW, int nx, const double* samples_dev, int64_t N,
+                            int64_t batch, int64_t batch_stride, double* m_out_dev, void* stream);
+
+/* Sampler description: w = xi_EV - xi_LV - B*u_LV with xi_* uniform on {x: Xi_A x <= Xi_b} by
+ * rejection from the bounding box [lo, hi] of the vertices, u_LV ~ U[min_u, max_u].
+ * Replaces Functions_general/InitialSetComputation.m:50-53,101-130 and
+ * Functions_general/ModelingCar.m:34-91.  The reference uses MATLAB's unseeded global `rand`;
+ * this library defines its own counter-based stream (Philox4x32-10, DESIGN.md "RNG"). */
+typedef struct lbmpc_sampler {
+    int nx, nu;
+    int nEV, nLV;              /* rows of the two H-reps                                  */
+    const double* EV_A;        /* nEV x nx */
+    const double* EV_b;        /* nEV      */
+    const double* EV_lo;       /* nx  bounding box of Xi_true_EV.V                        */
+    const double* EV_hi;       /* nx                                                      */
+    const double* LV_A;        /* nLV x nx */
+    const double* LV_b;
+    const double* LV_lo;
+    const double* LV_hi;
+    const double* B;           /* nx x nu  */
+    const double* min_u_LV;    /* nu       */
+    const double* max_u_LV;    /* nu       */
+} lbmpc_sampler;
+
+/* Draw `batch` information sets of N samples each (set b uses RNG stream (seed, set0 + b)),
+ * write them to samples_out (nx x N per set, sets contiguous; may be NULL to skip the store)
+ * and their halfspace maxima to m_out (nW x batch).  status_out (batch ints, may be NULL) gets
+ * LBMPC_ST_SAMPLER_CAP where a rejection loop hit `max_attempts`.
+ * Replaces the sampling loop + constraint build of InitialSetComputation.m:48-54. */
+int lbmpc_sample_information_sets(const lbmpc_sampler* smp, const double* WA, int nW, int64_t N,
+                                  int64_t batch, uint64_t seed, uint64_t set0, int max_attempts,
+                                  double* samples_out, double* m_out, int* status_out);
+int lbmpc_sample_information_sets_dev(const lbmpc_sampler* smp, const double* WA, int nW, int64_t N,
+                                      int64_t batch, uint64_t seed, uint64_t set0, int max_attempts,
+                                      double* samples_out_dev, double* m_out_dev, int* status_out_dev,
+                                      void* stream);
+
+/* The homothety LP  max beta  s.t. 0<=beta<=1, WA y <= beta Wb, beta Wb - WA y <= Wb - m
+ * (alpha = 1-beta, v = y/beta), one problem per column of m (nW x batch).
+ * Replaces Functions_general/InitialSetComputation.m:69-83,:85-99 (LP, LP_opt) and
+ * Functions_general/UQRobustMPC.m:124-139 (LPforUQ, with m = max(b_hat_prev, WA w_new)).
+ * alpha is unique; y is not (SURVEY.md hard part 1): tiebreak LBMPC_TIE_CENTER returns the
+ * midpoint of each coordinate's optimal interval (requires an axis-aligned box W, which is what
+ * every reference configuration uses; otherwise LBMPC_ERR_UNSUPPORTED).
+ * active_mask (batch x uint32, may be NULL): bit k set if axis k attains alpha (k < nx).
+ * status (batch ints, may be NULL): LBMPC_ST_LP_INFEASIBLE where some m_j > Wb_j. */
+#define LBMPC_TIE_CENTER 1
+int lbmpc_homothety_lp(const double* WA, const double* Wb, int nW, int nx, const double* m,
+                       int64_t batch, int tiebreak, double* alpha, double* v, uint32_t* active_mask,
+                       int* status);
+int lbmpc_homothety_lp_dev(const double* WA, const double* Wb, int nW, int nx, const double* m_dev,
+                           int64_t batch, int tiebreak, double* alpha_dev, double* v_dev,
+                           uint32_t* active_mask_dev, int* status_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Subsystem 3: the per-step tightened tube-MPC QP and the batched closed loop
+ * ---------------------------------------------------------------------------------------- */
+
+/* Fields mirror the `parameters` struct consumed by Functions_general/UQRobustMPC.m:39-62 and
+ * NominalRobustMPC.m:28-45 (Polyhedra unpacked to A,b).  All host pointers; copied at create. */
+typedef struct lbmpc_params {
+    int nx, nu, N, nc;
+    int Nu;               /* nu_s: constraint horizon, rows i = 0..Nu                     */
+    int nS, nW;
+    const double* A;      /* nx x nx */
+    const double* B;      /* nx x nu */
+    const double* K;      /* nu x nx */
+    const double* Phi;    /* nx x nx  (= A + B K) */
+    const double* Px;     /* nx x nx */
+    const double* Pc;     /* (N nu) x (N nu) */
+    const double* F;      /* nc x nx */
+    const double* G;      /* nc x nu */
+    const double* F_bar;  /* nc x (nx + N nu) */
+    const double* Psi;    /* (nx + N nu)^2 */
+    const double* S_A;    /* nS x nx */
+    const double* S_b;    /* nS */
+    const double* W_A;    /* nW x nx */
+    const double* W_b;    /* nW */
+    const double* hs;     /* nc : h_S((F+GK)_i) */
+} lbmpc_params;
+
+typedef struct lbmpc_ctx lbmpc_ctx;
+
+/* Build the device-resident constant block (constraint matrix [-S_A 0; F_bar Psi^i], (2P)^-1,
+ * T = (I-Phi)^-1, F_Com T, S_A T ...).  Replaces the constructors UQRobustMPC.m:39-66 /
+ * NominalRobustMPC.m:28-45 (which build CasADi Opti objects). *ctx_out = NULL on error. */
+int lbmpc_uqmpc_create(const lbmpc_params* p, lbmpc_ctx** ctx_out);
+void lbmpc_destroy(lbmpc_ctx* ctx);
+
+/* One UQ-RMPC step for `batch` independent problems (column b of every array is problem b).
+ * Replaces Functions_general/UQRobustMPC.m:68-91 (`solve`): online set update (LPforUQ), set
+ * algebra :75-78, h_k (:80-84, closed form alpha*hs + (1-alpha) F_Com T v), tube QP (:87),
+ * u_k = K x_k + c_0 (:90).
+ *   in : x (nx x batch), alpha_prev (batch), v_prev (nx x batch), w_new (nx x batch)
+ *   out: s0 (nx x batch), c (N nu x batch), u (nu x batch), alpha (batch), v (nx x batch),
+ *        hk (nc x batch), Sb_hat (nS x batch), Wb_hat (nW x batch), status (batch),
+ *        n_active (batch), active_set (LBMPC_MAX_NZ x batch, ascending row ids of the QP rows
+ *        [S rows 0..nS-1, then row nS + i*nc + r for F_bar Psi^i row r], -1 padded),
+ *        qp_iters (batch).  Any out pointer may be NULL.
+ * uq_update = 0 skips the set update (alpha = alpha_prev, v = v_prev): with alpha_prev = 1,
+ * v_prev = 0 this is Functions_general/NominalRobustMPC.m:47-52. */
+int lbmpc_uqmpc_step(lbmpc_ctx* ctx, int64_t batch, int uq_update, const double* x,
+                     const double* alpha_prev, const double* v_prev, const double* w_new, double* s0,
+                     double* c, double* u, double* alpha, double* v, double* hk, double* Sb_hat,
+                     double* Wb_hat, int* status, int* n_active, int* active_set, int* qp_iters);
+
+/* Batched closed-loop Monte-Carlo (the loops of Cases_general/Case_3...:57-88, Case_4...:32-66,
+ * Case_5...:55-98): per trial, learn (alpha0, v0) from card_I0 sampled disturbances
+ * (InitialSetComputation.solve), then `steps` UQ-RMPC steps against the sampled plant
+ * (ModelingCar.m:34-45) in relative coordinates x+ = A x + B u + xi_EV - xi_LV - B u_LV. */
+typedef struct lbmpc_mc_cfg {
+    int64_t trials;       /* trials run by this call                                       */
+    int64_t trial0;       /* global id of the first one (RNG stream key; multi-GPU shards) */
+    int32_t steps;        /* K_N                                                           */
+    int32_t card_I0;      /* N_pre_sam                                                     */
+    uint64_t seed;
+    const double* x0;     /* nx: initial relative state x_RM_0 (same for all trials)       */
+    double acc_bound;     /* |u| bound of the violation test, Case_5...:90-91              */
+    double distance_error;/* state bound of the violation test, Case_5...:92-93            */
+    double vol_W;         /* volume of the prior W (vol(W_hat) = alpha^nx vol_W)           */
+    int32_t traj_trials;  /* record full trajectories for the first traj_trials trials     */
+    int32_t sampler_max_attempts; /* 1000 in ModelingCar.m:54                              */
+} lbmpc_mc_cfg;
+
+typedef struct lbmpc_mc_out { /* device or host pointers depending on the entry point; any may be NULL */
+    int32_t* infeasible;  /* trials : Infeasible_Index of Case_5...:90-97                  */
+    int32_t* status;      /* trials : max status word seen                                 */
+    int32_t* qp_iters;    /* trials : total active-set iterations                          */
+    double* alpha_final;  /* trials                                                        */
+    double* v_final;      /* nx x trials                                                   */
+    double* alpha0;       /* trials : after the initial set learning                       */
+    double* x_final;      /* nx x trials                                                   */
+    double* traj_x;       /* nx x (steps+1) x traj_trials  (State_RM)                      */
+    double* traj_u;       /* nu x steps x traj_trials      (Control_EV)                    */
+    double* traj_alpha;   /* (steps+1) x traj_trials                                       */
+    double* traj_s0;      /* nx x steps x traj_trials      (Nominal_RM_State)              */
+} lbmpc_mc_out;
+
+int lbmpc_mc_run(lbmpc_ctx* ctx, const lbmpc_sampler* smp, const lbmpc_mc_cfg* cfg, lbmpc_mc_out* out);
+int lbmpc_mc_run_dev(lbmpc_ctx* ctx, const lbmpc_sampler* smp, const lbmpc_mc_cfg* cfg,
+                     lbmpc_mc_out* out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LBMPC_H */

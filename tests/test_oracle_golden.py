@@ -1,0 +1,272 @@
+"""Pin the CPU oracle (oracle/lbmpc_oracle.c) against every stored output of the reference that
+covers the hot path: Results_1 (set learning), stats_2x2 (solve_opt), Results_3_*
+(per-step KATs of UQRobustMPC.solve), parameters_2x2 (hs).  Tolerances vs the stored reference are
+the accuracy of IPOPT itself (alpha 5e-8, h_k 1.2e-8, s_0 3e-8, u 6e-8)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+from scipy.optimize import linprog
+
+import fixtures
+import oracle_ffi
+from lbmpc import _abi
+from lbmpc._abi import dptr, fcol, iptr
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return oracle_ffi.load()
+
+
+@pytest.fixture(scope="module")
+def P():
+    return fixtures.params_dict()
+
+
+def lp_rows(WA, Wb, m):
+    """rows R [beta; y] <= rhs of InitialSetComputation.m:74-79 after the max-reduction"""
+    nW, nx = WA.shape
+    R = np.zeros((2 * nW + 2, nx + 1))
+    rhs = np.zeros(2 * nW + 2)
+    R[:nW, 0], R[:nW, 1:] = -Wb, WA
+    R[nW:2 * nW, 0], R[nW:2 * nW, 1:], rhs[nW:2 * nW] = Wb, -WA, Wb - m
+    R[2 * nW, 0] = -1
+    R[2 * nW + 1, 0], rhs[2 * nW + 1] = 1, 1
+    return R, rhs
+
+
+def highs_alpha(WA, Wb, m):
+    R, rhs = lp_rows(WA, Wb, m)
+    c = np.zeros(R.shape[1])
+    c[0] = -1
+    res = linprog(c, A_ub=R, b_ub=rhs, bounds=[(None, None)] * R.shape[1], method="highs")
+    assert res.status == 0
+    return 1 - res.x[0]
+
+
+def halfspace_max(orc, WA, samples):
+    nW, nx = WA.shape
+    s = fcol(samples)
+    m = np.zeros(nW)
+    assert orc.orc_halfspace_max(dptr(fcol(WA)), nW, nx, dptr(s), s.shape[1], 1, s.size, dptr(m)) == 0
+    return m
+
+
+def box_lp(orc, WA, Wb, m):
+    nW, nx = WA.shape
+    a, v, mask, st = np.zeros(1), np.zeros(nx), np.zeros(1, np.uint32), np.zeros(1, np.int32)
+    rc = orc.orc_homothety_lp(dptr(fcol(WA)), dptr(fcol(Wb)), nW, nx, dptr(fcol(m)), 1, _abi.TIE_CENTER, dptr(a),
+                              dptr(v), mask.ctypes.data_as(_abi.c_uint32_p), iptr(st))
+    assert rc == 0
+    return a[0], v, int(mask[0]), int(st[0])
+
+
+def enum_lp(orc, WA, Wb, m):
+    nW, nx = WA.shape
+    a, v, y = np.zeros(1), np.zeros(nx), np.zeros(nx)
+    st = orc.orc_homothety_lp_enum(dptr(fcol(WA)), dptr(fcol(Wb)), nW, nx, dptr(fcol(m)), dptr(a), dptr(v), dptr(y))
+    return a[0], v, y, st
+
+
+EXACT_ALPHA_R1 = [0.0795854905, 0.1990103278, 0.2717102036, 0.3347049807, 0.3273450526]
+
+
+def test_results_1_set_learning(orc):
+    """Samples_ini{k} -> (Alpha_ini, V_ini, W_Hat_ini): InitialSetComputation.solve, Case_1...:29-42"""
+    R = fixtures.npz("results_1.npz")
+    WA, Wb = R["W_H"][:, :-1], R["W_H"][:, -1]
+    for i in range(5):
+        S = R[f"Samples_{i}"]
+        m = halfspace_max(orc, WA, S)
+        np.testing.assert_allclose(m, (WA @ S).max(axis=1), rtol=0, atol=1e-15)
+        a_enum, v_enum, y_enum, st = enum_lp(orc, WA, Wb, m)
+        assert st == 0
+        a_box, v_box, mask, st = box_lp(orc, WA, Wb, m)
+        assert st == 0 and mask != 0
+        a_highs = highs_alpha(WA, Wb, m)
+        # the three exact solvers agree; the reference (IPOPT) is the inexact one
+        assert abs(a_enum - a_highs) < 1e-12 and abs(a_box - a_enum) < 1e-13
+        assert abs(a_box - EXACT_ALPHA_R1[i]) < 1e-9
+        assert abs(a_box - R["Alpha_ini"][i]) < 1e-7
+        # canonical v and the reference's v are both in the optimal face (all LP rows hold at beta*)
+        Rm, rhs = lp_rows(WA, Wb, m)
+        for v, tol in ((v_box, 1e-12), (v_enum, 1e-10), (R["V_ini"][:, i], 1e-7)):
+            x = np.concatenate([[1 - a_box], (1 - a_box) * v])
+            assert (Rm @ x - rhs).max() < tol
+        # binding coordinate is pinned: reference and canonical agree there
+        for k in range(2):
+            if mask >> k & 1:
+                assert abs(v_box[k] - R["V_ini"][k, i]) < 2e-7
+        # W_hat = (1-alpha) v + alpha W in H-rep from the STORED (alpha, v)
+        a_ref, v_ref = R["Alpha_ini"][i], R["V_ini"][:, i]
+        H = R[f"W_Hat_{i}_H"]
+        np.testing.assert_allclose(H[:, :-1], WA, atol=1e-12)
+        np.testing.assert_allclose(H[:, -1], a_ref * Wb + (1 - a_ref) * WA @ v_ref, atol=1e-10)
+
+
+def test_stats_alpha_opt(orc, P):
+    """solve_opt(W_true.V') of offline_parameters_computation_nxn.m:357 -> stats.alpha_opt, v_opt"""
+    st = fixtures.npz("stats.npz")
+    WA, Wb = P["W_A"], P["W_b"]
+    m = halfspace_max(orc, WA, P["W_true_V"].T)
+    a, v, mask, status = box_lp(orc, WA, Wb, m)
+    assert status == 0
+    assert abs(a - 0.36746915025) < 1e-10
+    assert abs(a - st["2x2_alpha_opt"][0]) < 1e-7
+    assert mask == 0b10 and abs(v[1] - st["2x2_v_opt"][1]) < 1e-8
+    # same (alpha_opt, v_opt) is stored as W_hat_opt's H-rep
+    H = P["W_hat_opt_H"]
+    a_ref, v_ref = st["2x2_alpha_opt"][0], st["2x2_v_opt"]
+    np.testing.assert_allclose(H[:, -1], a_ref * Wb + (1 - a_ref) * WA @ v_ref, atol=1e-9)
+
+
+def test_hs_from_S_vertices(orc, P):
+    """hs = h_S((F+GK)_i) = max F_Com S.V'  (hs_debug_experiment.m:103-111; nxn.m:734)"""
+    Fc = P["F"] + P["G"] @ P["K"]
+    V = fcol(P["S_V"])
+    h = np.zeros(4)
+    I = fcol(np.eye(2))
+    assert orc.orc_support_batch(dptr(I), 2, dptr(V), V.shape[0], 1, 0.0, dptr(fcol(Fc.T)), 4, 0, dptr(h)) == 0
+    np.testing.assert_allclose(h, P["hs"].ravel(), atol=1.5e-8)
+    np.testing.assert_allclose(h, [0.1489621924, 0.1489621908, 0.929358463, 0.929358463], atol=1e-9)
+    # LP over the H-rep (UQRobustMPC.m:109-122) gives the same numbers
+    for i in range(4):
+        r = linprog(-Fc[i], A_ub=P["S_A"], b_ub=P["S_b"], bounds=[(None, None)] * 2, method="highs")
+        assert abs(-r.fun - h[i]) < 1e-8
+
+
+def recover_alpha_v(WA, Wb, bh):
+    """invert b_hat = alpha b + (1-alpha) W_A v for the 2x2 box W (rows: -y, +x, +y, -x)"""
+    c = np.abs(WA).max(axis=1)
+    ax = np.abs(WA).argmax(axis=1)
+    sg = np.sign(WA[np.arange(len(ax)), ax])
+    nx = WA.shape[1]
+    alpha, v = None, np.zeros(nx)
+    for k in range(nx):
+        p = [j for j in range(len(ax)) if ax[j] == k and sg[j] > 0][0]
+        q = [j for j in range(len(ax)) if ax[j] == k and sg[j] < 0][0]
+        a_k = (bh[p] / c[p] + bh[q] / c[q]) / (Wb[p] / c[p] + Wb[q] / c[q])
+        alpha = a_k if alpha is None else alpha
+        assert abs(a_k - alpha) < 1e-9
+    for k in range(nx):
+        p = [j for j in range(len(ax)) if ax[j] == k and sg[j] > 0][0]
+        v[k] = (bh[p] / c[p] - alpha * Wb[p] / c[p]) / (1 - alpha)
+    return alpha, v
+
+
+def results3_context(orc, P, R):
+    """Results_3_* were produced with a 102-row S that is not in the checkout: take
+    S_A from the stored S_hat, recover S_b from step 0, and hs by LP over that S."""
+    WA, Wb = P["W_A"], P["W_b"]
+    T = np.linalg.inv(np.eye(2) - P["Phi"])
+    a0, v0 = recover_alpha_v(WA, Wb, R["W_Hat_H"][0][:, -1])
+    SA = R["S_Hat_H"][0][:, :-1]
+    Sb = (R["S_Hat_H"][0][:, -1] - (1 - a0) * SA @ T @ v0) / a0
+    Fc = P["F"] + P["G"] @ P["K"]
+    hs = np.array([-linprog(-Fc[i], A_ub=SA, b_ub=Sb, bounds=[(None, None)] * 2, method="highs").fun for i in range(4)])
+    d = dict(P)
+    d.update(S_A=SA, S_b=Sb, hs=hs)
+    kp = _abi.make_params(d)
+    ctx = C.c_void_p()
+    assert orc.orc_uqmpc_create(kp.ref(), C.byref(ctx)) == 0
+    return ctx, kp, d, T
+
+
+def step(orc, ctx, d, uq, x, a_prev, v_prev, w):
+    nx, nc, nS, nW, ncv = 2, 4, d["S_A"].shape[0], 4, 8
+    o = dict(s0=np.zeros(nx), c=np.zeros(ncv), u=np.zeros(1), alpha=np.zeros(1), v=np.zeros(nx), hk=np.zeros(nc),
+             Sb=np.zeros(nS), Wb=np.zeros(nW))
+    st, na, act, it = (np.zeros(1, np.int32), np.zeros(1, np.int32), np.zeros(_abi.MAX_NZ, np.int32),
+                       np.zeros(1, np.int32))
+    rc = orc.orc_uqmpc_step(ctx, 1, uq, dptr(fcol(x)), dptr(np.array([a_prev])), dptr(fcol(v_prev)), dptr(fcol(w)),
+                            dptr(o["s0"]), dptr(o["c"]), dptr(o["u"]), dptr(o["alpha"]), dptr(o["v"]), dptr(o["hk"]),
+                            dptr(o["Sb"]), dptr(o["Wb"]), iptr(st), iptr(na), iptr(act), iptr(it))
+    assert rc == 0
+    o.update(status=int(st[0]), n_active=int(na[0]), active=act[:int(na[0])].copy(), iters=int(it[0]))
+    return o
+
+
+@pytest.mark.parametrize("tag", ["small", "large"])
+def test_results_3_per_step_kats(orc, P, tag):
+    """50 stored steps of Case_3: (x_k, b_hat_{k-1}, w_k) -> alpha_k; (alpha_k, v_k) -> S_hat.b, h_k;
+    (x_k, h_k, S_hat_k) -> (s_0, u_k)."""
+    R = fixtures.npz(f"results_3_{tag}.npz")
+    ctx, kp, d, T = results3_context(orc, P, R)
+    WA, Wb = P["W_A"], P["W_b"]
+    A, B = P["A"], P["B"]
+    X, U, S0, HS = R["State_RM"], R["Control_EV"], R["Nominal_RM_State"], R["Hs"]
+    av = [recover_alpha_v(WA, Wb, R["W_Hat_H"][k][:, -1]) for k in range(50)]
+    n_active_seen = 0
+    for k in range(50):
+        a_k, v_k = av[k]
+        # stage KATs are fed the reference's own (alpha_k, v_k) (hard part 1: v is not unique)
+        o = step(orc, ctx, d, 0, X[:, k], a_k, v_k, np.zeros(2))
+        assert o["status"] == 0
+        np.testing.assert_allclose(o["Sb"], R["S_Hat_H"][k][:, -1], atol=2e-9)
+        np.testing.assert_allclose(o["Wb"], R["W_Hat_H"][k][:, -1], atol=1e-12)
+        np.testing.assert_allclose(o["hk"], HS[:, k], atol=1.5e-8)
+        np.testing.assert_allclose(o["s0"], S0[:, k], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(o["u"], U[:, k], rtol=1e-6, atol=1e-6)
+        n_active_seen = max(n_active_seen, o["n_active"])
+        if k >= 1:
+            # online update LPforUQ (UQRobustMPC.m:124-139): alpha is pinned, v only where binding
+            w = X[:, k] - A @ X[:, k - 1] - B[:, 0] * U[0, k - 1]
+            o2 = step(orc, ctx, d, 1, X[:, k], av[k - 1][0], av[k - 1][1], w)
+            assert abs(o2["alpha"][0] - a_k) < 1e-7
+    assert n_active_seen >= 1  # the transient really exercises the active-set path
+    orc.orc_destroy(ctx)
+
+
+def kkt_check(d, ctxdata, x, alpha, v, o, T):
+    """independent KKT verification of the oracle's QP answer (primal/dual feasibility, stationarity)"""
+    nx = 2
+    SA, Sb, H = d["S_A"], d["S_b"], ctxdata
+    z = np.concatenate([o["s0"], o["c"]])
+    Sb_hat = alpha * Sb + (1 - alpha) * SA @ T @ v
+    Cm = np.vstack([np.hstack([-SA, np.zeros((SA.shape[0], z.size - nx))]), H])
+    dv = np.concatenate([Sb_hat - SA @ x, np.tile(1 - o["hk"], H.shape[0] // 4)])
+    slack = dv - Cm @ z
+    assert slack.min() > -1e-9
+    Pm = np.zeros((z.size, z.size))
+    Pm[:nx, :nx] = d["Px"]
+    Pm[nx:, nx:] = d["Pc"]
+    act = o["active"]
+    if len(act) == 0:
+        assert np.abs(z).max() < 1e-12
+        return
+    assert np.abs(slack[act]).max() < 1e-9
+    lam, res, *_ = np.linalg.lstsq(Cm[act].T, -2 * Pm @ z, rcond=None)
+    assert np.abs(Cm[act].T @ lam + 2 * Pm @ z).max() < 1e-8
+    assert lam.min() > -1e-9
+
+
+def test_qp_kkt_random_states(orc, P):
+    """The oracle's Goldfarb-Idnani QP satisfies the KKT conditions of UQRobustMPC.m:149-155 on states
+    spread over the feasible region (and reports infeasibility outside it)."""
+    d = dict(P)
+    kp = _abi.make_params(d)
+    ctx = C.c_void_p()
+    assert orc.orc_uqmpc_create(kp.ref(), C.byref(ctx)) == 0
+    nH, nz = 4 * (int(P["Nu"]) + 1), 10
+    H = np.zeros((nH, nz))
+    assert orc.orc_ctx_export(ctx, dptr(H), None, None, None) == 0
+    Href = np.vstack([P["F_bar"] @ np.linalg.matrix_power(P["Psi"], i) for i in range(int(P["Nu"]) + 1)])
+    np.testing.assert_allclose(H, Href, atol=1e-12)
+    T = np.linalg.inv(np.eye(2) - P["Phi"])
+    rng = np.random.default_rng(0)
+    V = P["F_N_RMPC_V"]
+    n_act, n_inf = 0, 0
+    for t in range(200):
+        lamb = rng.dirichlet(np.ones(3))
+        x = (V[rng.integers(0, len(V), 3)] * lamb[:, None]).sum(0) * rng.uniform(0.2, 1.0)
+        alpha, v = rng.uniform(0.1, 1.0), rng.uniform(-0.05, 0.05, 2)
+        o = step(orc, ctx, d, 0, x, alpha, v, np.zeros(2))
+        assert o["status"] == 0, (t, x)
+        kkt_check(d, H, x, alpha, v, o, T)
+        n_act += o["n_active"] > 0
+    assert n_act > 50
+    # far outside the feasible region the QP has no solution: the oracle says so (the reference cannot)
+    o = step(orc, ctx, d, 0, np.array([40.0, 10.0]), 0.5, np.zeros(2), np.zeros(2))
+    assert o["status"] == _abi.ST_QP_INFEASIBLE
+    orc.orc_destroy(ctx)
