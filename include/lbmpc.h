@@ -49,7 +49,8 @@ extern "C" {
 #define LBMPC_MAX_NZ 16 /* nx + N*nu */
 #define LBMPC_MAX_NC 16
 #define LBMPC_MAX_NW 16
-#define LBMPC_MAX_NXI 32 /* rows of Xi_true_EV / Xi_true_LV H-rep */
+#define LBMPC_MAX_NXI 16 /* rows of Xi_true_EV / Xi_true_LV H-rep */
+#define LBMPC_MAX_NU 4  /* inputs (subsystem 3) */
 #define LBMPC_MAX_NV 1024 /* vertices of the V-rep in the support sweep; also s*nV <= 2048 */
 #define LBMPC_MAX_S 64   /* terms of the Minkowski sum            */
 

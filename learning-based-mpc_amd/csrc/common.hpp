@@ -1,0 +1,241 @@
+// common.hpp -- shared host/device helpers of liblbmpc_hip.so (gfx950 only).
+//
+// Arithmetic contract (DESIGN.md "Arithmetic contract"): the library is built with
+// -ffp-contract=off; every dot product is an explicit fma chain in ascending index order from a
+// stated initial value; max/min reductions are order-free; argmin ties go to the lowest row.  The
+// CPU oracle follows the same contract, so flags, active sets and maxima agree exactly.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lbmpc.h"
+
+namespace lbmpc {
+
+// ---- host-side error plumbing -----------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_device();  // 0 if lbmpc_init succeeded on this process, else LBMPC_ERR_NODEVICE
+
+#define LB_HIP(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            ::lbmpc::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+            return LBMPC_ERR_HIP;                                                         \
+        }                                                                                 \
+    } while (0)
+
+// RAII device buffer for the host-pointer entry points
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
+
+// ---- device helpers ---------------------------------------------------------------------------
+#define LB_WAVE 64
+#define LB_INF __builtin_inf()
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (LB_WAVE - 1); }
+
+// Orders LDS traffic of one wave: LDS ops of a wave execute in issue order, so a compiler-level
+// fence plus a wave barrier is enough to hand data between lanes of the same wave through LDS.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int src_lane /* wave-uniform */) {
+    union { double d; int i[2]; } a, b;
+    a.d = v;
+    b.i[0] = __builtin_amdgcn_readlane(a.i[0], src_lane);
+    b.i[1] = __builtin_amdgcn_readlane(a.i[1], src_lane);
+    return b.d;
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        double o = __shfl_xor(v, off, LB_WAVE);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// (value, index) arg-min with ties to the lowest index; every lane gets the result.
+__device__ __forceinline__ void wave_argmin(double& v, int& idx) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        double ov = __shfl_xor(v, off, LB_WAVE);
+        int oi = __shfl_xor(idx, off, LB_WAVE);
+        bool take = (ov < v) || (ov == v && oi < idx);
+        v = take ? ov : v;
+        idx = take ? oi : idx;
+    }
+}
+
+// ---- RNG: Philox4x32-10, bit-identical to oracle/lbmpc_oracle.c ------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+__device__ __forceinline__ double u01(uint32_t lo, uint32_t hi) {
+    uint64_t x = ((uint64_t)hi << 32) | lo;
+    return (double)(x >> 11) * 0x1.0p-53;
+}
+
+enum { P_I0_U = 0, P_I0_EV = 1, P_I0_LV = 2, P_ST_LV = 3, P_ST_U = 4, P_ST_EV = 5 };
+
+template <int N>
+__device__ __forceinline__ void draw_uniforms(uint64_t seed, uint64_t trial, uint32_t index,
+                                              uint32_t purpose, uint32_t attempt, double* out) {
+#pragma unroll
+    for (int blk = 0; 2 * blk < N; ++blk) {
+        uint32_t c[4] = {(uint32_t)trial, (uint32_t)(trial >> 32), index,
+                         (purpose << 28) | (attempt << 4) | (uint32_t)blk};
+        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        out[2 * blk] = u01(c[0], c[1]);
+        if (2 * blk + 1 < N) out[2 * blk + 1] = u01(c[2], c[3]);
+    }
+}
+
+// Device-resident description of the two disturbance polytopes + input range (lbmpc_sampler),
+// rows stored row-major.  Read through wave-uniform (scalar) loads.
+struct SamplerDev {
+    int nx, nu, nEV, nLV;
+    double EV_A[LBMPC_MAX_NXI * LBMPC_MAX_NX], EV_b[LBMPC_MAX_NXI], EV_lo[LBMPC_MAX_NX], EV_hi[LBMPC_MAX_NX];
+    double LV_A[LBMPC_MAX_NXI * LBMPC_MAX_NX], LV_b[LBMPC_MAX_NXI], LV_lo[LBMPC_MAX_NX], LV_hi[LBMPC_MAX_NX];
+    double B[LBMPC_MAX_NX * LBMPC_MAX_NU];  // row-major nx x nu
+    double min_u[LBMPC_MAX_NU], max_u[LBMPC_MAX_NU];
+};
+int pack_sampler(const lbmpc_sampler* s, SamplerDev* out);  // host: validate + repack
+
+// Rejection sampling from the vertex bounding box against A x <= b
+// (InitialSetComputation.m:101-122, ModelingCar.m:47-91).  Returns true at the attempt cap.
+template <int NX>
+__device__ __forceinline__ bool sample_polytope(const double* __restrict__ XA, const double* __restrict__ Xb,
+                                                int nr, const double* __restrict__ lo,
+                                                const double* __restrict__ hi, uint64_t seed, uint64_t trial,
+                                                uint32_t index, uint32_t purpose, int max_attempts, double* x) {
+    bool done = false;
+    for (int a = 0; a < max_attempts; ++a) {
+        if (!done) {
+            double u[NX + (NX & 1)];
+            double xt[NX];
+            draw_uniforms<NX>(seed, trial, index, purpose, (uint32_t)a, u);
+#pragma unroll
+            for (int k = 0; k < NX; ++k) xt[k] = lo[k] + (hi[k] - lo[k]) * u[k];
+            bool ok = true;
+            for (int r = 0; r < nr; ++r) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < NX; ++k) acc = fma(XA[r * NX + k], xt[k], acc);
+                ok = ok && (acc <= Xb[r]);
+            }
+#pragma unroll
+            for (int k = 0; k < NX; ++k) x[k] = xt[k];
+            done = ok;
+        }
+        if (__builtin_amdgcn_ballot_w64(!done) == 0) break;  // every active lane accepted
+    }
+    return !done;
+}
+
+// u_LV ~ U[min_u, max_u]^nu; returns B u (nx).  nu <= 2 uses one Philox block.
+template <int NX>
+__device__ __forceinline__ void sample_Bu_lv(const SamplerDev* __restrict__ s, uint64_t seed, uint64_t trial,
+                                             uint32_t index, uint32_t purpose, double* Bu) {
+    double acc[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) acc[i] = 0.0;
+    const int nu = s->nu;
+    for (int blk = 0; 2 * blk < nu; ++blk) {
+        uint32_t c[4] = {(uint32_t)trial, (uint32_t)(trial >> 32), index, (purpose << 28) | (uint32_t)blk};
+        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        double r0 = u01(c[0], c[1]), r1 = u01(c[2], c[3]);
+        int j0 = 2 * blk, j1 = 2 * blk + 1;
+        double u0 = (s->max_u[j0] - s->min_u[j0]) * r0 + s->min_u[j0];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) acc[i] = fma(s->B[i * nu + j0], u0, acc[i]);
+        if (j1 < nu) {
+            double u1 = (s->max_u[j1] - s->min_u[j1]) * r1 + s->min_u[j1];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[i] = fma(s->B[i * nu + j1], u1, acc[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) Bu[i] = acc[i];
+}
+
+// One information-set sample w = xi_EV - xi_LV - B u_LV (InitialSetComputation.m:51-52)
+template <int NX>
+__device__ __forceinline__ bool sample_w_I0(const SamplerDev* __restrict__ s, uint64_t seed, uint64_t set,
+                                            uint32_t i, int max_attempts, double* w) {
+    double ev[NX], lv[NX], Bu[NX];
+    sample_Bu_lv<NX>(s, seed, set, i, P_I0_U, Bu);
+    bool cap = sample_polytope<NX>(s->EV_A, s->EV_b, s->nEV, s->EV_lo, s->EV_hi, seed, set, i, P_I0_EV, max_attempts, ev);
+    cap |= sample_polytope<NX>(s->LV_A, s->LV_b, s->nLV, s->LV_lo, s->LV_hi, seed, set, i, P_I0_LV, max_attempts, lv);
+#pragma unroll
+    for (int k = 0; k < NX; ++k) w[k] = (ev[k] - lv[k]) - Bu[k];
+    return cap;
+}
+
+// Box structure of the prior W in canonical row order: row 2k = +e_k row, row 2k+1 = -e_k row.
+struct BoxW {
+    int nx, nW;
+    int perm[LBMPC_MAX_NW];                    // canonical row r is caller row perm[r]
+    double WA[LBMPC_MAX_NW * LBMPC_MAX_NX];    // canonical rows, row-major (caller's values)
+    double Wb[LBMPC_MAX_NW];
+    double ic[LBMPC_MAX_NW];                   // 1 / |axis coefficient|
+};
+int pack_box(const double* WA, const double* Wb, int nW, int nx, BoxW* out);  // host
+
+// Closed form of the homothety LP for a box W with the LBMPC_TIE_CENTER rule; `m` in canonical
+// row order.  Same operation order as orc_homothety_box.
+template <int NX>
+__device__ __forceinline__ int homothety_box(const BoxW* __restrict__ bw, const double* m, double& alpha,
+                                             double* v, uint32_t& mask) {
+    double Bp[NX], Bq[NX], Mp[NX], Mq[NX], rho[NX];
+    bool infeas = false;
+    double a = 0.0;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+        const int p = 2 * k, q = 2 * k + 1;
+        Bp[k] = bw->Wb[p] * bw->ic[p]; Bq[k] = bw->Wb[q] * bw->ic[q];
+        Mp[k] = m[p] * bw->ic[p];      Mq[k] = m[q] * bw->ic[q];
+        infeas = infeas || (m[p] > bw->Wb[p]) || (m[q] > bw->Wb[q]);
+        rho[k] = (Mp[k] + Mq[k]) / (Bp[k] + Bq[k]);
+        a = rho[k] > a ? rho[k] : a;
+    }
+    if (infeas) {
+        alpha = 1.0; mask = 0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) v[k] = 0.0;
+        return LBMPC_ST_LP_INFEASIBLE;
+    }
+    const double beta = 1.0 - a;
+    uint32_t mk = 0;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+        double lo1 = Mp[k] - a * Bp[k], lo2 = -(beta * Bq[k]);
+        double hi1 = beta * Bp[k], hi2 = a * Bq[k] - Mq[k];
+        double lo = lo1 > lo2 ? lo1 : lo2;
+        double hi = hi1 < hi2 ? hi1 : hi2;
+        double y = 0.5 * (lo + hi);
+        v[k] = beta > 0.0 ? y / beta : 0.0;
+        if (a > 0.0 && rho[k] >= a) mk |= 1u << k;
+    }
+    alpha = a; mask = mk;
+    return 0;
+}
+
+}  // namespace lbmpc

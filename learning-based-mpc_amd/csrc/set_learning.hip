@@ -1,0 +1,444 @@
+// set_learning.hip -- subsystem 2: homothetic disturbance-set learning over I_0^w.
+//
+//   halfspace_max_kernel : m[b,j] = max_i W_A[j,:].w_{b,i}   (HBM stream, 8*nx bytes/sample)
+//   sample_sets_kernel   : on-device generation of the information sets + their maxima
+//   homothety_lp_kernel  : the (nx+1)-variable LP in closed form, one lane per information set
+//
+// Replaces Functions_general/InitialSetComputation.m:48-99 (sampling loop, LP build, IPOPT solve)
+// and the sample rows of Functions_general/UQRobustMPC.m:124-139.
+#include "common.hpp"
+
+namespace lbmpc {
+
+struct RowsW {  // W_A rows (caller order), row-major, passed by value -> scalar registers
+    double a[LBMPC_MAX_NW * LBMPC_MAX_NX];
+};
+
+// ---- halfspace max ----------------------------------------------------------------------------
+// One wave per (information set, chunk) unit.  Lane l owns SPL consecutive samples per step, so a
+// lane's load is SPL*NX*8 bytes (a multiple of 16 when VEC: read as double2), wave-contiguous.
+// UNR independent steps are kept in flight.  Partial maxima go to part[(b*chunks + c)*NW + j].
+template <int NX, int NW, int SPL, bool VEC>
+__global__ __launch_bounds__(256) void halfspace_max_kernel(const double* __restrict__ samples, int64_t N,
+                                                            int64_t batch, int64_t stride, int chunks,
+                                                            int64_t spc /* samples per chunk, multiple of 64*SPL */,
+                                                            RowsW W, double* __restrict__ part) {
+    const int lane = lane_id();
+    const int64_t unit = (int64_t)blockIdx.x * (blockDim.x / LB_WAVE) + (threadIdx.x / LB_WAVE);
+    if (unit >= batch * chunks) return;
+    const int64_t b = unit / chunks;
+    const int c = (int)(unit % chunks);
+    const double* __restrict__ S = samples + b * stride;
+    const int64_t i0 = (int64_t)c * spc;
+    const int64_t i1 = (i0 + spc < N) ? i0 + spc : N;
+
+    double m[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) m[j] = -LB_INF;
+
+    constexpr int UNR = 4;
+    constexpr int PER = SPL * NX;  // doubles per lane per step
+    int64_t i = i0 + (int64_t)lane * SPL;
+    // full steps: all SPL samples of all UNR steps of this lane in range
+    for (; i + (int64_t)(UNR - 1) * 64 * SPL + SPL <= i1; i += (int64_t)UNR * 64 * SPL) {
+        double w[UNR][PER];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const double* p = S + (i + (int64_t)u * 64 * SPL) * NX;
+            if constexpr (VEC) {
+#pragma unroll
+                for (int q = 0; q < PER / 2; ++q) {
+                    double2 t = reinterpret_cast<const double2*>(p)[q];
+                    w[u][2 * q] = t.x; w[u][2 * q + 1] = t.y;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < PER; ++q) w[u][q] = p[q];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+            for (int s = 0; s < SPL; ++s)
+#pragma unroll
+                for (int j = 0; j < NW; ++j) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) acc = fma(W.a[j * NX + k], w[u][s * NX + k], acc);
+                    m[j] = acc > m[j] ? acc : m[j];
+                }
+    }
+    // tail: one sample at a time
+    for (; i < i1; i += 64 * SPL) {
+        for (int s = 0; s < SPL && i + s < i1; ++s) {
+            const double* p = S + (i + s) * NX;
+            double w[NX];
+#pragma unroll
+            for (int k = 0; k < NX; ++k) w[k] = p[k];
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < NX; ++k) acc = fma(W.a[j * NX + k], w[k], acc);
+                m[j] = acc > m[j] ? acc : m[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) m[j] = wave_max(m[j]);
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) part[unit * NW + j] = m[j];
+    }
+}
+
+// generic row count (nW not 2*nx): rows looped at run time in groups of 4
+template <int NX>
+__global__ __launch_bounds__(256) void halfspace_max_generic_kernel(const double* __restrict__ samples, int64_t N,
+                                                                    int64_t batch, int64_t stride, int chunks,
+                                                                    int64_t spc, int nW, RowsW W,
+                                                                    double* __restrict__ part) {
+    const int lane = lane_id();
+    const int64_t unit = (int64_t)blockIdx.x * (blockDim.x / LB_WAVE) + (threadIdx.x / LB_WAVE);
+    if (unit >= batch * chunks) return;
+    const int64_t b = unit / chunks;
+    const int c = (int)(unit % chunks);
+    const double* __restrict__ S = samples + b * stride;
+    const int64_t i0 = (int64_t)c * spc;
+    const int64_t i1 = (i0 + spc < N) ? i0 + spc : N;
+    double m[LBMPC_MAX_NW];
+#pragma unroll
+    for (int j = 0; j < LBMPC_MAX_NW; ++j) m[j] = -LB_INF;
+    for (int64_t i = i0 + lane; i < i1; i += 64) {
+        double w[NX];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) w[k] = S[i * NX + k];
+#pragma unroll
+        for (int j = 0; j < LBMPC_MAX_NW; ++j)
+            if (j < nW) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < NX; ++k) acc = fma(W.a[j * NX + k], w[k], acc);
+                m[j] = acc > m[j] ? acc : m[j];
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < LBMPC_MAX_NW; ++j)
+        if (j < nW) {
+            double r = wave_max(m[j]);
+            if (lane == 0) part[unit * nW + j] = r;
+        }
+}
+
+__global__ void finish_max_kernel(const double* __restrict__ part, int64_t batch, int chunks, int nW,
+                                  double* __restrict__ m_out) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= batch * nW) return;
+    int64_t b = t / nW;
+    int j = (int)(t % nW);
+    double m = -LB_INF;
+    for (int c = 0; c < chunks; ++c) {
+        double x = part[(b * chunks + c) * nW + j];
+        m = x > m ? x : m;
+    }
+    m_out[t] = m;
+}
+
+static void pack_rows(const double* WA, int nW, int nx, RowsW* r) {
+    for (int j = 0; j < nW; ++j)
+        for (int k = 0; k < nx; ++k) r->a[j * nx + k] = WA[j + (size_t)nW * k];
+}
+
+template <int NX, int NW, int SPL>
+static void launch_hmax(bool vec, dim3 grid, hipStream_t st, const double* s, int64_t N, int64_t batch,
+                        int64_t stride, int chunks, int64_t spc, const RowsW& W, double* part) {
+    if (vec)
+        hipLaunchKernelGGL((halfspace_max_kernel<NX, NW, SPL, true>), grid, dim3(256), 0, st, s, N, batch, stride, chunks, spc, W, part);
+    else
+        hipLaunchKernelGGL((halfspace_max_kernel<NX, NW, SPL, false>), grid, dim3(256), 0, st, s, N, batch, stride, chunks, spc, W, part);
+}
+
+// chunking: enough wave-units to fill 256 CUs x 32 waves twice, chunk a multiple of the lane step
+static void plan_chunks(int64_t N, int64_t batch, int spl, int* chunks, int64_t* spc) {
+    const int64_t step = 64 * spl * 4;  // one full unrolled step of a wave
+    const int64_t want_units = 256 * 32 * 2;
+    int64_t c = (want_units + batch - 1) / batch;
+    int64_t maxc = (N + step - 1) / step;
+    if (c > maxc) c = maxc;
+    if (c < 1) c = 1;
+    if (c > 65535) c = 65535;
+    int64_t per = (N + c - 1) / c;
+    per = ((per + step - 1) / step) * step;
+    c = (N + per - 1) / per;
+    *chunks = (int)c;
+    *spc = per;
+}
+
+}  // namespace lbmpc
+
+using namespace lbmpc;
+
+// Scratch for the partial maxima when an information set is split over several waves.  Grown on
+// demand per device, released by lbmpc_shutdown... kept simple: allocate/free per call when needed.
+extern "C" int lbmpc_halfspace_max_dev(const double* WA, int nW, int nx, const double* samples_dev, int64_t N,
+                                       int64_t batch, int64_t batch_stride, double* m_out_dev, void* stream) {
+    if (int rc = check_device()) return rc;
+    if (!WA || !samples_dev || !m_out_dev || N < 1 || batch < 0 || nW < 1 || nx < 1) {
+        set_error("lbmpc_halfspace_max: bad argument");
+        return LBMPC_ERR_ARG;
+    }
+    if (nx > LBMPC_MAX_NX || nW > LBMPC_MAX_NW) { set_error("lbmpc_halfspace_max: nx<=%d, nW<=%d", LBMPC_MAX_NX, LBMPC_MAX_NW); return LBMPC_ERR_DIM; }
+    if (batch > 1 && batch_stride < N * nx) { set_error("lbmpc_halfspace_max: batch_stride < N*nx"); return LBMPC_ERR_ARG; }
+    if (batch == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    RowsW W;
+    pack_rows(WA, nW, nx, &W);
+    const int spl = (nx == 1) ? 2 : (nx == 3 ? 2 : 1);
+    int chunks; int64_t spc;
+    plan_chunks(N, batch, spl, &chunks, &spc);
+    const int64_t units = batch * chunks;
+    dim3 grid((unsigned)((units + 3) / 4));
+    double* part = m_out_dev;
+    void* tmp = nullptr;
+    if (chunks > 1) {
+        LB_HIP(hipMallocAsync(&tmp, sizeof(double) * units * nW, st));
+        part = (double*)tmp;
+    }
+    const bool vec = ((uintptr_t)samples_dev % 16 == 0) && ((batch_stride * 8) % 16 == 0 || batch == 1);
+    const bool boxrows = (nW == 2 * nx);
+    if (boxrows && nx == 1) launch_hmax<1, 2, 2>(vec, grid, st, samples_dev, N, batch, batch_stride, chunks, spc, W, part);
+    else if (boxrows && nx == 2) launch_hmax<2, 4, 1>(vec, grid, st, samples_dev, N, batch, batch_stride, chunks, spc, W, part);
+    else if (boxrows && nx == 3) launch_hmax<3, 6, 2>(vec, grid, st, samples_dev, N, batch, batch_stride, chunks, spc, W, part);
+    else if (boxrows && nx == 4) launch_hmax<4, 8, 1>(vec, grid, st, samples_dev, N, batch, batch_stride, chunks, spc, W, part);
+    else {
+        // generic kernel steps one sample per lane: chunk boundaries need no SPL alignment
+        switch (nx) {
+            case 1: hipLaunchKernelGGL(halfspace_max_generic_kernel<1>, grid, dim3(256), 0, st, samples_dev, N, batch, batch_stride, chunks, spc, nW, W, part); break;
+            case 2: hipLaunchKernelGGL(halfspace_max_generic_kernel<2>, grid, dim3(256), 0, st, samples_dev, N, batch, batch_stride, chunks, spc, nW, W, part); break;
+            case 3: hipLaunchKernelGGL(halfspace_max_generic_kernel<3>, grid, dim3(256), 0, st, samples_dev, N, batch, batch_stride, chunks, spc, nW, W, part); break;
+            default: hipLaunchKernelGGL(halfspace_max_generic_kernel<4>, grid, dim3(256), 0, st, samples_dev, N, batch, batch_stride, chunks, spc, nW, W, part); break;
+        }
+    }
+    LB_HIP(hipGetLastError());
+    if (chunks > 1) {
+        int64_t n = batch * nW;
+        hipLaunchKernelGGL(finish_max_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, batch, chunks, nW, m_out_dev);
+        LB_HIP(hipGetLastError());
+        LB_HIP(hipFreeAsync(tmp, st));
+    }
+    return 0;
+}
+
+extern "C" int lbmpc_halfspace_max(const double* WA, int nW, int nx, const double* samples, int64_t N,
+                                   int64_t batch, int64_t batch_stride, double* m_out) {
+    if (int rc = check_device()) return rc;
+    if (!samples || !m_out || N < 1 || batch < 0 || nx < 1 || nW < 1) { set_error("lbmpc_halfspace_max: bad argument"); return LBMPC_ERR_ARG; }
+    if (batch == 0) return 0;
+    if (batch > 1 && batch_stride < N * nx) { set_error("lbmpc_halfspace_max: batch_stride < N*nx"); return LBMPC_ERR_ARG; }
+    const size_t total = (size_t)((batch - 1) * batch_stride + N * nx);
+    DevBuf ds, dm;
+    LB_HIP(ds.alloc(total * sizeof(double)));
+    LB_HIP(dm.alloc((size_t)batch * nW * sizeof(double)));
+    LB_HIP(hipMemcpy(ds.p, samples, total * sizeof(double), hipMemcpyHostToDevice));
+    int rc = lbmpc_halfspace_max_dev(WA, nW, nx, ds.as<double>(), N, batch, batch_stride, dm.as<double>(), nullptr);
+    if (rc) return rc;
+    LB_HIP(hipMemcpy(m_out, dm.p, (size_t)batch * nW * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- on-device information-set generation -------------------------------------------------------
+namespace lbmpc {
+
+// One wave per information set; lane l draws samples l, l+64, ...  (stream (seed, set0+b), index i).
+template <int NX>
+__global__ __launch_bounds__(256) void sample_sets_kernel(SamplerDev smp, RowsW W, int nW,
+                                                          int64_t N, int64_t batch, uint64_t seed, uint64_t set0,
+                                                          int max_attempts, double* __restrict__ samples_out,
+                                                          double* __restrict__ m_out, int* __restrict__ status_out) {
+    const int lane = lane_id();
+    const int64_t b = (int64_t)blockIdx.x * (blockDim.x / LB_WAVE) + (threadIdx.x / LB_WAVE);
+    if (b >= batch) return;
+    double m[LBMPC_MAX_NW];
+#pragma unroll
+    for (int j = 0; j < LBMPC_MAX_NW; ++j) m[j] = -LB_INF;
+    bool cap = false;
+    for (int64_t i = lane; i < N; i += 64) {
+        double w[NX];
+        cap |= sample_w_I0<NX>(&smp, seed, set0 + (uint64_t)b, (uint32_t)i, max_attempts, w);
+        if (samples_out) {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) samples_out[(b * N + i) * NX + k] = w[k];
+        }
+#pragma unroll
+        for (int j = 0; j < LBMPC_MAX_NW; ++j)
+            if (j < nW) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < NX; ++k) acc = fma(W.a[j * NX + k], w[k], acc);
+                m[j] = acc > m[j] ? acc : m[j];
+            }
+    }
+    const bool anycap = __builtin_amdgcn_ballot_w64(cap) != 0;
+#pragma unroll
+    for (int j = 0; j < LBMPC_MAX_NW; ++j)
+        if (j < nW) {
+            double r = wave_max(m[j]);
+            if (lane == 0 && m_out) m_out[b * nW + j] = r;
+        }
+    if (lane == 0 && status_out) status_out[b] = anycap ? LBMPC_ST_SAMPLER_CAP : 0;
+}
+
+int pack_sampler(const lbmpc_sampler* s, SamplerDev* o) {
+    if (!s || !s->EV_A || !s->EV_b || !s->EV_lo || !s->EV_hi || !s->LV_A || !s->LV_b || !s->LV_lo || !s->LV_hi ||
+        !s->B || !s->min_u_LV || !s->max_u_LV) { set_error("lbmpc_sampler: null field"); return LBMPC_ERR_ARG; }
+    if (s->nx < 1 || s->nu < 1 || s->nEV < 1 || s->nLV < 1) { set_error("lbmpc_sampler: bad size"); return LBMPC_ERR_ARG; }
+    if (s->nx > LBMPC_MAX_NX || s->nu > LBMPC_MAX_NU || s->nEV > LBMPC_MAX_NXI || s->nLV > LBMPC_MAX_NXI) { set_error("lbmpc_sampler: dimension limit"); return LBMPC_ERR_DIM; }
+    o->nx = s->nx; o->nu = s->nu; o->nEV = s->nEV; o->nLV = s->nLV;
+    for (int r = 0; r < s->nEV; ++r) { for (int k = 0; k < s->nx; ++k) o->EV_A[r * s->nx + k] = s->EV_A[r + (size_t)s->nEV * k]; o->EV_b[r] = s->EV_b[r]; }
+    for (int r = 0; r < s->nLV; ++r) { for (int k = 0; k < s->nx; ++k) o->LV_A[r * s->nx + k] = s->LV_A[r + (size_t)s->nLV * k]; o->LV_b[r] = s->LV_b[r]; }
+    for (int k = 0; k < s->nx; ++k) { o->EV_lo[k] = s->EV_lo[k]; o->EV_hi[k] = s->EV_hi[k]; o->LV_lo[k] = s->LV_lo[k]; o->LV_hi[k] = s->LV_hi[k]; }
+    for (int i = 0; i < s->nx; ++i) for (int j = 0; j < s->nu; ++j) o->B[i * s->nu + j] = s->B[i + (size_t)s->nx * j];
+    for (int j = 0; j < s->nu; ++j) { o->min_u[j] = s->min_u_LV[j]; o->max_u[j] = s->max_u_LV[j]; }
+    return 0;
+}
+
+}  // namespace lbmpc
+
+extern "C" int lbmpc_sample_information_sets_dev(const lbmpc_sampler* smp, const double* WA, int nW, int64_t N,
+                                                 int64_t batch, uint64_t seed, uint64_t set0, int max_attempts,
+                                                 double* samples_out_dev, double* m_out_dev, int* status_out_dev,
+                                                 void* stream) {
+    if (int rc = check_device()) return rc;
+    if (!WA || N < 1 || batch < 0 || nW < 1 || max_attempts < 1) { set_error("lbmpc_sample_information_sets: bad argument"); return LBMPC_ERR_ARG; }
+    if (nW > LBMPC_MAX_NW) return LBMPC_ERR_DIM;
+    if (N > 0xffffffffLL) { set_error("lbmpc_sample_information_sets: N exceeds the 32-bit sample index"); return LBMPC_ERR_DIM; }
+    SamplerDev h;
+    if (int rc = pack_sampler(smp, &h)) return rc;
+    if (batch == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    RowsW W;
+    pack_rows(WA, nW, h.nx, &W);
+    dim3 grid((unsigned)((batch + 3) / 4));
+    const SamplerDev& d = h;
+    switch (h.nx) {
+        case 1: hipLaunchKernelGGL(sample_sets_kernel<1>, grid, dim3(256), 0, st, d, W, nW, N, batch, seed, set0, max_attempts, samples_out_dev, m_out_dev, status_out_dev); break;
+        case 2: hipLaunchKernelGGL(sample_sets_kernel<2>, grid, dim3(256), 0, st, d, W, nW, N, batch, seed, set0, max_attempts, samples_out_dev, m_out_dev, status_out_dev); break;
+        case 3: hipLaunchKernelGGL(sample_sets_kernel<3>, grid, dim3(256), 0, st, d, W, nW, N, batch, seed, set0, max_attempts, samples_out_dev, m_out_dev, status_out_dev); break;
+        default: hipLaunchKernelGGL(sample_sets_kernel<4>, grid, dim3(256), 0, st, d, W, nW, N, batch, seed, set0, max_attempts, samples_out_dev, m_out_dev, status_out_dev); break;
+    }
+    LB_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int lbmpc_sample_information_sets(const lbmpc_sampler* smp, const double* WA, int nW, int64_t N,
+                                             int64_t batch, uint64_t seed, uint64_t set0, int max_attempts,
+                                             double* samples_out, double* m_out, int* status_out) {
+    if (int rc = check_device()) return rc;
+    if (!smp || batch < 0 || N < 1 || nW < 1) { set_error("lbmpc_sample_information_sets: bad argument"); return LBMPC_ERR_ARG; }
+    if (batch == 0) return 0;
+    const int nx = smp->nx;
+    DevBuf ds, dm, dst;
+    if (samples_out) LB_HIP(ds.alloc((size_t)batch * N * nx * sizeof(double)));
+    LB_HIP(dm.alloc((size_t)batch * nW * sizeof(double)));
+    LB_HIP(dst.alloc((size_t)batch * sizeof(int)));
+    int rc = lbmpc_sample_information_sets_dev(smp, WA, nW, N, batch, seed, set0, max_attempts,
+                                               samples_out ? ds.as<double>() : nullptr, dm.as<double>(), dst.as<int>(), nullptr);
+    if (rc) return rc;
+    LB_HIP(hipDeviceSynchronize());
+    if (samples_out) LB_HIP(hipMemcpy(samples_out, ds.p, (size_t)batch * N * nx * sizeof(double), hipMemcpyDeviceToHost));
+    if (m_out) LB_HIP(hipMemcpy(m_out, dm.p, (size_t)batch * nW * sizeof(double), hipMemcpyDeviceToHost));
+    if (status_out) LB_HIP(hipMemcpy(status_out, dst.p, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- homothety LP -------------------------------------------------------------------------------
+namespace lbmpc {
+
+int pack_box(const double* WA, const double* Wb, int nW, int nx, BoxW* o) {
+    if (!WA || !Wb) { set_error("W: null pointer"); return LBMPC_ERR_ARG; }
+    if (nx < 1 || nx > LBMPC_MAX_NX || nW > LBMPC_MAX_NW) return LBMPC_ERR_DIM;
+    if (nW != 2 * nx) { set_error("prior W must be an axis-aligned box (nW == 2 nx); got nW=%d nx=%d", nW, nx); return LBMPC_ERR_UNSUPPORTED; }
+    o->nx = nx; o->nW = nW;
+    for (int r = 0; r < nW; ++r) o->perm[r] = -1;
+    for (int j = 0; j < nW; ++j) {
+        int ax = 0;
+        for (int k = 1; k < nx; ++k) if (fabs(WA[j + (size_t)nW * k]) > fabs(WA[j + (size_t)nW * ax])) ax = k;
+        const double a = WA[j + (size_t)nW * ax];
+        if (a == 0.0) { set_error("W row %d is zero", j); return LBMPC_ERR_UNSUPPORTED; }
+        for (int k = 0; k < nx; ++k)
+            if (k != ax && fabs(WA[j + (size_t)nW * k]) > 1e-12 * fabs(a)) { set_error("W row %d is not axis-aligned", j); return LBMPC_ERR_UNSUPPORTED; }
+        const int r = 2 * ax + (a > 0 ? 0 : 1);
+        if (o->perm[r] >= 0) { set_error("W has two rows for the same face"); return LBMPC_ERR_UNSUPPORTED; }
+        o->perm[r] = j;
+        o->ic[r] = 1.0 / fabs(a);
+    }
+    for (int r = 0; r < nW; ++r) {
+        if (o->perm[r] < 0) { set_error("W is unbounded along an axis"); return LBMPC_ERR_UNSUPPORTED; }
+        for (int k = 0; k < nx; ++k) o->WA[r * nx + k] = WA[o->perm[r] + (size_t)nW * k];
+        o->Wb[r] = Wb[o->perm[r]];
+    }
+    return 0;
+}
+
+template <int NX>
+__global__ void homothety_lp_kernel(BoxW bw, const double* __restrict__ m, int64_t batch, double* __restrict__ alpha,
+                                    double* __restrict__ v, uint32_t* __restrict__ mask_out, int* __restrict__ status) {
+    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    double mm[2 * NX], vv[NX], a;
+    uint32_t mk;
+#pragma unroll
+    for (int r = 0; r < 2 * NX; ++r) mm[r] = m[b * 2 * NX + bw.perm[r]];
+    int st = homothety_box<NX>(&bw, mm, a, vv, mk);
+    alpha[b] = a;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) v[b * NX + k] = vv[k];
+    if (mask_out) mask_out[b] = mk;
+    if (status) status[b] = st;
+}
+
+}  // namespace lbmpc
+
+extern "C" int lbmpc_homothety_lp_dev(const double* WA, const double* Wb, int nW, int nx, const double* m_dev,
+                                      int64_t batch, int tiebreak, double* alpha_dev, double* v_dev,
+                                      uint32_t* active_mask_dev, int* status_dev, void* stream) {
+    if (int rc = check_device()) return rc;
+    if (!m_dev || !alpha_dev || !v_dev || batch < 0) { set_error("lbmpc_homothety_lp: bad argument"); return LBMPC_ERR_ARG; }
+    if (tiebreak != LBMPC_TIE_CENTER) { set_error("lbmpc_homothety_lp: unknown tiebreak %d", tiebreak); return LBMPC_ERR_ARG; }
+    BoxW bw;
+    if (int rc = pack_box(WA, Wb, nW, nx, &bw)) return rc;
+    if (batch == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)((batch + 255) / 256));
+    switch (nx) {
+        case 1: hipLaunchKernelGGL(homothety_lp_kernel<1>, grid, dim3(256), 0, st, bw, m_dev, batch, alpha_dev, v_dev, active_mask_dev, status_dev); break;
+        case 2: hipLaunchKernelGGL(homothety_lp_kernel<2>, grid, dim3(256), 0, st, bw, m_dev, batch, alpha_dev, v_dev, active_mask_dev, status_dev); break;
+        case 3: hipLaunchKernelGGL(homothety_lp_kernel<3>, grid, dim3(256), 0, st, bw, m_dev, batch, alpha_dev, v_dev, active_mask_dev, status_dev); break;
+        default: hipLaunchKernelGGL(homothety_lp_kernel<4>, grid, dim3(256), 0, st, bw, m_dev, batch, alpha_dev, v_dev, active_mask_dev, status_dev); break;
+    }
+    LB_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int lbmpc_homothety_lp(const double* WA, const double* Wb, int nW, int nx, const double* m,
+                                  int64_t batch, int tiebreak, double* alpha, double* v, uint32_t* active_mask,
+                                  int* status) {
+    if (int rc = check_device()) return rc;
+    if (!m || !alpha || !v || batch < 0 || nW < 1 || nx < 1) { set_error("lbmpc_homothety_lp: bad argument"); return LBMPC_ERR_ARG; }
+    if (batch == 0) return 0;
+    DevBuf dm, da, dv, dk, ds;
+    LB_HIP(dm.alloc((size_t)batch * nW * sizeof(double)));
+    LB_HIP(da.alloc((size_t)batch * sizeof(double)));
+    LB_HIP(dv.alloc((size_t)batch * nx * sizeof(double)));
+    LB_HIP(dk.alloc((size_t)batch * sizeof(uint32_t)));
+    LB_HIP(ds.alloc((size_t)batch * sizeof(int)));
+    LB_HIP(hipMemcpy(dm.p, m, (size_t)batch * nW * sizeof(double), hipMemcpyHostToDevice));
+    int rc = lbmpc_homothety_lp_dev(WA, Wb, nW, nx, dm.as<double>(), batch, tiebreak, da.as<double>(), dv.as<double>(),
+                                    dk.as<uint32_t>(), ds.as<int>(), nullptr);
+    if (rc) return rc;
+    LB_HIP(hipMemcpy(alpha, da.p, (size_t)batch * sizeof(double), hipMemcpyDeviceToHost));
+    LB_HIP(hipMemcpy(v, dv.p, (size_t)batch * nx * sizeof(double), hipMemcpyDeviceToHost));
+    if (active_mask) LB_HIP(hipMemcpy(active_mask, dk.p, (size_t)batch * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (status) LB_HIP(hipMemcpy(status, ds.p, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}

@@ -1,0 +1,208 @@
+// support.hip -- subsystem 1: batched support functions for the mRPI set / tube tightening.
+//
+//   h_S(d) = (1-alpha)^-1 sum_{t<s} h_W(P_t d),  h_W(p) = max_v V_W[v,:].p,  P_t = (A^t)' or A^t
+//
+// Replaces MPT3 `W.support(...)` (one LP / vertex scan per column) at Functions_general/MRPISet.m:29,45
+// and the nc support LPs per MPC step of UQRobustMPC.m:109-122 when S is the Minkowski-sum polytope.
+// The s*nV stacked rows G_t = V_W P_t' are wave-uniform: they are read through scalar loads (they
+// fit the scalar cache for every W of the reference: nV <= 16, s <= ~30) and feed v_fma_f64 as SGPR
+// operands, so the sweep is bound by the fp64 vector rate, not by LDS or HBM (DESIGN.md "Kernel 1").
+#include <cmath>
+#include <vector>
+
+#include "common.hpp"
+
+namespace lbmpc {
+
+// One lane = DPL directions (lane + 64 u), all s*nV rows applied to each.
+template <int NX, int DPL, bool VEC>
+__global__ __launch_bounds__(256) void support_kernel(const double* __restrict__ G /* s x nV x NX row-major */,
+                                                      int s, int nV, double scale, const double* __restrict__ D,
+                                                      int64_t nd, double* __restrict__ h_out) {
+    const int64_t base = ((int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63)) * DPL + (threadIdx.x & 63);
+    double d[DPL][NX], sum[DPL];
+#pragma unroll
+    for (int u = 0; u < DPL; ++u) {
+        const int64_t i = base + (int64_t)u * 64;
+        const int64_t ii = i < nd ? i : (nd - 1);
+        const double* p = D + ii * NX;
+        if constexpr (VEC && (NX % 2 == 0)) {
+#pragma unroll
+            for (int q = 0; q < NX / 2; ++q) {
+                double2 t = reinterpret_cast<const double2*>(p)[q];
+                d[u][2 * q] = t.x; d[u][2 * q + 1] = t.y;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) d[u][k] = p[k];
+        }
+        sum[u] = 0.0;
+    }
+    const double* __restrict__ g = G;
+    for (int t = 0; t < s; ++t) {
+        double best[DPL];
+#pragma unroll
+        for (int u = 0; u < DPL; ++u) best[u] = -LB_INF;
+        for (int v = 0; v < nV; ++v, g += NX) {
+            double a[NX];
+#pragma unroll
+            for (int k = 0; k < NX; ++k) a[k] = g[k];
+#pragma unroll
+            for (int u = 0; u < DPL; ++u) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < NX; ++k) acc = fma(a[k], d[u][k], acc);
+                best[u] = acc > best[u] ? acc : best[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < DPL; ++u) sum[u] += best[u];
+    }
+#pragma unroll
+    for (int u = 0; u < DPL; ++u) {
+        const int64_t i = base + (int64_t)u * 64;
+        if (i < nd) h_out[i] = sum[u] * scale;
+    }
+}
+
+// host: G[t] = Vw P_t'  (nV x nx row-major per t), P_t = A^t (transpose_flag: (A^t)')
+static void stack_G(const double* A, int nx, const double* Vw, int nV, int s, int transpose_flag, std::vector<double>& G) {
+    G.assign((size_t)s * nV * nx, 0.0);
+    double P[16], Q[16];
+    for (int i = 0; i < nx; ++i) for (int j = 0; j < nx; ++j) P[i + nx * j] = (i == j) ? 1.0 : 0.0;  // column-major A^t
+    for (int t = 0; t < s; ++t) {
+        double* Gt = G.data() + (size_t)t * nV * nx;
+        for (int v = 0; v < nV; ++v)
+            for (int k = 0; k < nx; ++k) {
+                double acc = 0.0;
+                for (int j = 0; j < nx; ++j) {
+                    const double pjk = transpose_flag ? P[k + nx * j] : P[j + nx * k];
+                    acc = std::fma(Vw[v + (size_t)nV * j], pjk, acc);
+                }
+                Gt[v * nx + k] = acc;
+            }
+        for (int i = 0; i < nx; ++i)
+            for (int j = 0; j < nx; ++j) {
+                double acc = 0.0;
+                for (int k = 0; k < nx; ++k) acc = std::fma(P[i + nx * k], A[k + nx * j], acc);
+                Q[i + nx * j] = acc;
+            }
+        for (int i = 0; i < nx * nx; ++i) P[i] = Q[i];
+    }
+}
+
+static int launch_support(const double* Gdev, int nx, int s, int nV, double scale, const double* D, int64_t nd,
+                          double* out, hipStream_t st) {
+    if (nd == 0) return 0;
+    const bool vec = ((uintptr_t)D % 16) == 0;
+    const bool wide = nd >= (int64_t)256 * 8 * 256 * 4;  // enough work for 4 directions per lane
+#define LS(NXV, DPLV)                                                                                              \
+    do {                                                                                                           \
+        const int64_t per_block = 256 * (int64_t)DPLV;                                                             \
+        dim3 grid((unsigned)((nd + per_block - 1) / per_block));                                                   \
+        if (vec) hipLaunchKernelGGL((support_kernel<NXV, DPLV, true>), grid, dim3(256), 0, st, Gdev, s, nV, scale, D, nd, out); \
+        else hipLaunchKernelGGL((support_kernel<NXV, DPLV, false>), grid, dim3(256), 0, st, Gdev, s, nV, scale, D, nd, out);    \
+    } while (0)
+    switch (nx) {
+        case 1: if (wide) LS(1, 4); else LS(1, 1); break;
+        case 2: if (wide) LS(2, 4); else LS(2, 1); break;
+        case 3: if (wide) LS(3, 4); else LS(3, 1); break;
+        default: if (wide) LS(4, 4); else LS(4, 1); break;
+    }
+#undef LS
+    LB_HIP(hipGetLastError());
+    return 0;
+}
+
+static int check_support_args(const double* A, int nx, const double* Vw, int nV, int s) {
+    if (!A || !Vw || nx < 1 || nV < 1 || s < 1) { set_error("support: bad argument"); return LBMPC_ERR_ARG; }
+    if (nx > LBMPC_MAX_NX || nV > LBMPC_MAX_NV || s > LBMPC_MAX_S || (int64_t)s * nV > 2048) {
+        set_error("support: limits nx<=%d nV<=%d s<=%d s*nV<=2048", LBMPC_MAX_NX, LBMPC_MAX_NV, LBMPC_MAX_S);
+        return LBMPC_ERR_DIM;
+    }
+    return 0;
+}
+
+}  // namespace lbmpc
+
+using namespace lbmpc;
+
+extern "C" int lbmpc_support_batch_dev(const double* A, int nx, const double* Vw, int nV, int s, double alpha,
+                                       const double* D_dev, int64_t nd, int transpose_flag, double* h_out_dev,
+                                       void* stream) {
+    if (int rc = check_device()) return rc;
+    if (int rc = check_support_args(A, nx, Vw, nV, s)) return rc;
+    if (!D_dev || !h_out_dev || nd < 0) { set_error("lbmpc_support_batch: bad argument"); return LBMPC_ERR_ARG; }
+    if (nd == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<double> G;
+    stack_G(A, nx, Vw, nV, s, transpose_flag, G);
+    void* dG = nullptr;
+    LB_HIP(hipMallocAsync(&dG, G.size() * 8, st));
+    LB_HIP(hipMemcpyAsync(dG, G.data(), G.size() * 8, hipMemcpyHostToDevice, st));
+    LB_HIP(hipStreamSynchronize(st));  // G is a stack temporary
+    int rc = launch_support((const double*)dG, nx, s, nV, 1.0 / (1.0 - alpha), D_dev, nd, h_out_dev, st);
+    (void)hipFreeAsync(dG, st);
+    return rc;
+}
+
+extern "C" int lbmpc_support_batch(const double* A, int nx, const double* Vw, int nV, int s, double alpha,
+                                   const double* D, int64_t nd, int transpose_flag, double* h_out) {
+    if (int rc = check_device()) return rc;
+    if (int rc = check_support_args(A, nx, Vw, nV, s)) return rc;
+    if (!D || !h_out || nd < 0) { set_error("lbmpc_support_batch: bad argument"); return LBMPC_ERR_ARG; }
+    if (nd == 0) return 0;
+    DevBuf dD, dh;
+    LB_HIP(dD.alloc((size_t)nd * nx * 8));
+    LB_HIP(dh.alloc((size_t)nd * 8));
+    LB_HIP(hipMemcpy(dD.p, D, (size_t)nd * nx * 8, hipMemcpyHostToDevice));
+    int rc = lbmpc_support_batch_dev(A, nx, Vw, nV, s, alpha, dD.as<double>(), nd, transpose_flag, dh.as<double>(), nullptr);
+    if (rc) return rc;
+    LB_HIP(hipMemcpy(h_out, dh.p, (size_t)nd * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// (s, alpha) search: MRPISet.m:27-63 (mode 0), Functions/MRPISet.m:8-17 (mode 1), Rakovic (mode 2).
+// Every support value is evaluated on the device (one small launch per s for the nW + ndirs directions).
+extern "C" int lbmpc_mrpi_s_alpha(const double* A, int nx, const double* Vw, int nV, const double* WA,
+                                  const double* Wb, int nW, const double* Dirs, int ndirs, double eps, int mode,
+                                  int max_s, int* s_out, double* alpha_out, double* Ms_out) {
+    if (int rc = check_device()) return rc;
+    if (!WA || !Wb || !Dirs || !s_out || !alpha_out || nW < 1 || ndirs < 1 || max_s < 1 || mode < 0 || mode > 2) { set_error("lbmpc_mrpi_s_alpha: bad argument"); return LBMPC_ERR_ARG; }
+    if (max_s > LBMPC_MAX_S - 1) max_s = LBMPC_MAX_S - 1;
+    if (int rc = check_support_args(A, nx, Vw, nV, 1)) return rc;
+    if (nW > LBMPC_MAX_NW) return LBMPC_ERR_DIM;
+    const int tr = (mode == LBMPC_MS_RAKOVIC);
+    std::vector<double> G;
+    stack_G(A, nx, Vw, nV, max_s + 1, tr, G);
+    // direction batch: [f_0 .. f_{nW-1} | Dirs]
+    const int nb = nW + ndirs;
+    std::vector<double> Dh((size_t)nb * nx), hh(nb);
+    for (int j = 0; j < nW; ++j) for (int k = 0; k < nx; ++k) Dh[(size_t)j * nx + k] = WA[j + (size_t)nW * k];
+    for (int d = 0; d < ndirs; ++d) for (int k = 0; k < nx; ++k) Dh[(size_t)(nW + d) * nx + k] = Dirs[(size_t)d * nx + k];
+    DevBuf dG, dD, dh;
+    LB_HIP(dG.alloc(G.size() * 8)); LB_HIP(dD.alloc(Dh.size() * 8)); LB_HIP(dh.alloc((size_t)nb * 8));
+    LB_HIP(hipMemcpy(dG.p, G.data(), G.size() * 8, hipMemcpyHostToDevice));
+    LB_HIP(hipMemcpy(dD.p, Dh.data(), Dh.size() * 8, hipMemcpyHostToDevice));
+    std::vector<double> sums(ndirs, 0.0);
+    double alpha = 1000.0, Ms = 1000.0, Mmax = -INFINITY;
+    int s = 0, rc = 0;
+    while (alpha > eps / (eps + Ms)) {
+        if (s >= max_s) { rc = LBMPC_ST_ITER_CAP; break; }
+        s += 1;
+        const int tnew = tr ? s - 1 : s;
+        const double* Gs = dG.as<double>() + (size_t)s * nV * nx;
+        const double* Gt = dG.as<double>() + (size_t)tnew * nV * nx;
+        if (int e = launch_support(Gs, nx, 1, nV, 1.0, dD.as<double>(), nW, dh.as<double>(), nullptr)) return e;
+        if (int e = launch_support(Gt, nx, 1, nV, 1.0, dD.as<double>() + (size_t)nW * nx, ndirs, dh.as<double>() + nW, nullptr)) return e;
+        LB_HIP(hipMemcpy(hh.data(), dh.p, (size_t)nb * 8, hipMemcpyDeviceToHost));
+        alpha = -INFINITY;
+        for (int j = 0; j < nW; ++j) { double a = hh[j] / Wb[j]; if (a > alpha) alpha = a; }
+        for (int d = 0; d < ndirs; ++d) { double h = hh[nW + d]; sums[d] += h; if (h > Mmax) Mmax = h; }
+        if (mode == LBMPC_MS_MAX_LITERAL) Ms = Mmax;
+        else { Ms = -INFINITY; for (int d = 0; d < ndirs; ++d) if (sums[d] > Ms) Ms = sums[d]; }
+    }
+    *s_out = s; *alpha_out = alpha;
+    if (Ms_out) *Ms_out = Ms;
+    return rc;
+}

@@ -1,0 +1,928 @@
+// uqmpc.hip -- subsystem 3: the per-step tightened tube-MPC QP and the batched closed loop.
+//
+// Replaces Functions_general/UQRobustMPC.m:68-159 (solve, LPforUQ, LP/Com_hs, MPCFormulation:
+// 2+nc IPOPT solves per step), NominalRobustMPC.m:47-69, ModelingCar.m:34-91 and the Monte-Carlo
+// loops of Cases_general/Case_{3,4,5}.
+//
+// Execution model (DESIGN.md "Kernel 3"):
+//   * a wave owns 64*T independent problems / trials, one per lane (T per lane);
+//   * phase A (lane-per-trial): plant sampling, online set update (closed-form homothety LP), h_k
+//     in closed form, and the first pass over the QP rows at the unconstrained minimiser z = 0
+//     (only the nS rows of S_hat can differ from their right-hand side there); the row
+//     coefficients are LDS broadcasts shared by the 64*T trials of the wave;
+//   * phase B (wave-cooperative, only for trials whose first pass found a violated row): the
+//     Goldfarb-Idnani dual active-set method; the 64 lanes stride the m constraint rows (one LDS
+//     row per lane, odd row pitch => conflict-free), arg-min by wave shuffles, the <=16x16
+//     Cholesky factor / KKT vectors live in a per-wave LDS workspace and registers;
+//   * phase C (lane-per-trial): u = K x + c_0, plant update, violation flags.
+// Constants ([S_b | S_A] rows, F_bar Psi^i rows, (2P)^-1) are staged once per block into LDS.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "common.hpp"
+
+namespace lbmpc {
+
+#define QP_TOL_VIOL 1e-10
+#define QP_TOL_DEP 1e-13
+#define QP_TOL_R 1e-12
+#define QP_MAX_ITERS 200
+#define NZMAX LBMPC_MAX_NZ
+
+struct CtxDev {
+    int nx, nu, N, nc, Nu, nS, nW, nz, nH, RL, nzp;
+    double A[LBMPC_MAX_NX * LBMPC_MAX_NX];    // row-major
+    double B[LBMPC_MAX_NX * LBMPC_MAX_NU];    // row-major nx x nu
+    double K[LBMPC_MAX_NU * LBMPC_MAX_NX];    // row-major nu x nx
+    double T[LBMPC_MAX_NX * LBMPC_MAX_NX];    // (I-Phi)^-1 row-major
+    double FcT[LBMPC_MAX_NC * LBMPC_MAX_NX];  // (F+GK) T row-major
+    double hs[LBMPC_MAX_NC];
+    BoxW box;
+    const double* Srow;  // nS x RL : [S_b[j], S_A[j,0..nx-1], pad]
+    const double* Hm;    // nH x nzp: rows of F_bar Psi^i, i = 0..Nu
+    const double* Ginv;  // nz x nz : (2 blkdiag(Px,Pc))^-1
+};
+
+}  // namespace lbmpc
+
+struct lbmpc_ctx {
+    lbmpc::CtxDev h;          // host copy (device pointers inside)
+    lbmpc::CtxDev* d = nullptr;
+    double *dS = nullptr, *dH = nullptr, *dG = nullptr;
+    int device = 0;
+    size_t lds_const_bytes = 0;
+};
+
+namespace lbmpc {
+
+struct LdsView {
+    const double* Srow;
+    const double* Hm;
+    const double* Ginv;
+};
+struct WsView {  // per-wave solver workspace in LDS
+    double *z, *g, *rhs, *omh, *Wm, *L;
+    int* act;
+};
+__host__ __device__ inline int ws_doubles(int nz) { return 72 + 2 * nz * nz; }
+__device__ __forceinline__ WsView ws_view(double* base, int nz) {
+    WsView w;
+    w.z = base; w.g = base + 16; w.rhs = base + 32; w.omh = base + 48;
+    w.act = reinterpret_cast<int*>(base + 64);
+    w.Wm = base + 72; w.L = base + 72 + nz * nz;
+    return w;
+}
+
+// coefficient k of QP row p (c_p of c_p.z <= d_p): S rows are [-S_A[j,:], 0], H rows F_bar Psi^i
+__device__ __forceinline__ double row_coef(const CtxDev* __restrict__ C, const LdsView& L, int p, int k) {
+    if (p < C->nS) return k < C->nx ? -L.Srow[p * C->RL + 1 + k] : 0.0;
+    return L.Hm[(p - C->nS) * C->nzp + k];
+}
+// c_p . w for a length-nz LDS vector w (fma chain from 0, ascending k; zero coefficients skipped,
+// which is exact)
+__device__ __forceinline__ double row_dot(const CtxDev* __restrict__ C, const LdsView& L, int p, const double* w) {
+    double acc = 0.0;
+    if (p < C->nS) {
+        for (int k = 0; k < C->nx; ++k) acc = fma(-L.Srow[p * C->RL + 1 + k], w[k], acc);
+    } else {
+        const double* h = L.Hm + (p - C->nS) * C->nzp;
+        for (int k = 0; k < C->nz; ++k) acc = fma(h[k], w[k], acc);
+    }
+    return acc;
+}
+
+// Append row `a` (constraint pa, wave-uniform) to the Cholesky factor of M = C_A Ginv C_A'.
+// Uniform sequential work executed redundantly by all lanes; lane 0 stores the row.
+__device__ __forceinline__ void chol_append(const CtxDev* __restrict__ C, const LdsView& L, const WsView& ws,
+                                            int a, int pa, int lane) {
+    const int nz = C->nz;
+    double Lrow[NZMAX];
+#pragma unroll
+    for (int b = 0; b < NZMAX; ++b) {
+        if (b <= a) {
+            double acc = row_dot(C, L, pa, ws.Wm + b * nz);
+#pragma unroll
+            for (int k = 0; k < NZMAX; ++k)
+                if (k < b) acc = fma(-Lrow[k], ws.L[b * nz + k], acc);
+            if (b < a) Lrow[b] = acc / ws.L[b * nz + b];
+            else Lrow[b] = sqrt(acc > 0.0 ? acc : 0.0);
+        }
+    }
+    wave_sync();
+    if (lane == 0) {
+#pragma unroll
+        for (int b = 0; b < NZMAX; ++b)
+            if (b <= a) ws.L[a * nz + b] = Lrow[b];
+    }
+    wave_sync();
+}
+
+// Wave-cooperative Goldfarb-Idnani dual active-set solve of
+//   min z'Pz  s.t.  alpha S_b + S_A (q + s0) >= 0,  (1-h) - H z >= 0      (UQRobustMPC.m:149-155)
+// from z = 0.  alpha, q[] wave-uniform; ws.omh[] holds 1-h_k.  (p0, sp0) = first pivot found by the
+// caller's pass at z = 0.  Result: ws.z, ws.act[0..nact).  Same arithmetic as the oracle's qp_solve.
+template <int NX>
+__device__ int coop_qp_solve(const CtxDev* __restrict__ C, const LdsView& L, const WsView& ws, double alpha,
+                             const double* q, int p0, double sp0, int& nact_out, int& iters_out) {
+    const int lane = lane_id();
+    const int nz = C->nz, nS = C->nS, nH = C->nH, nc = C->nc, RL = C->RL, nzp = C->nzp;
+    int nq = 0, iters = 0, status = 0;
+    uint64_t actS = 0, actH = 0;  // bit i: my i-th S row (lane + 64 i) / H row is active
+    double u[NZMAX + 1];
+#pragma unroll
+    for (int a = 0; a <= NZMAX; ++a) u[a] = 0.0;
+    if (lane < NZMAX) ws.z[lane] = 0.0;
+    wave_sync();
+    int p = p0;
+    double sp = sp0;
+    bool have_pivot = true;
+    for (;;) {
+        if (!have_pivot) {
+            // Step 1: most violated row at the current z
+            double zr[NZMAX], e[NX];
+#pragma unroll
+            for (int k = 0; k < NZMAX; ++k) zr[k] = (k < nz) ? ws.z[k] : 0.0;
+#pragma unroll
+            for (int k = 0; k < NX; ++k) e[k] = q[k] + zr[k];
+            double best = -QP_TOL_VIOL;
+            int bj = 0x7fffffff;
+            int i = 0;
+            for (int j = lane; j < nS; j += LB_WAVE, ++i) {
+                const double* row = L.Srow + j * RL;
+                double acc = alpha * row[0];
+#pragma unroll
+                for (int k = 0; k < NX; ++k) acc = fma(row[1 + k], e[k], acc);
+                if (!((actS >> i) & 1) && acc < best) { best = acc; bj = j; }
+            }
+            int r = lane % nc;
+            const int rstep = LB_WAVE % nc;
+            i = 0;
+            for (int h = lane; h < nH; h += LB_WAVE, ++i) {
+                const double* row = L.Hm + h * nzp;
+                double acc = ws.omh[r];
+#pragma unroll
+                for (int k = 0; k < NZMAX; ++k)
+                    if (k < nz) acc = fma(-row[k], zr[k], acc);
+                if (!((actH >> i) & 1) && acc < best) { best = acc; bj = nS + h; }
+                r += rstep;
+                if (r >= nc) r -= nc;
+            }
+            wave_argmin(best, bj);
+            if (bj == 0x7fffffff) break;  // optimal
+            p = bj; sp = best;
+        }
+        have_pivot = false;
+        // g = Ginv c_p ; cg = c_p . g
+        if (lane < nz) {
+            double acc = 0.0;
+            if (p < nS) { for (int k = 0; k < NX; ++k) acc = fma(L.Ginv[lane * nz + k], -L.Srow[p * RL + 1 + k], acc); }
+            else { const double* h = L.Hm + (p - nS) * nzp; for (int k = 0; k < nz; ++k) acc = fma(L.Ginv[lane * nz + k], h[k], acc); }
+            ws.g[lane] = acc;
+        }
+        wave_sync();
+        const double cg = row_dot(C, L, p, ws.g);
+        u[nq < NZMAX ? nq : NZMAX] = 0.0;  // u[nq] = 0 (static indexing below)
+#pragma unroll
+        for (int a = 0; a <= NZMAX; ++a) if (a == nq) u[a] = 0.0;
+        // Step 2
+        bool added = false;
+        while (!added) {
+            if (++iters > QP_MAX_ITERS) { status = LBMPC_ST_ITER_CAP; goto done; }
+            double r[NZMAX];
+#pragma unroll
+            for (int a = 0; a < NZMAX; ++a) r[a] = 0.0;
+            double delta = cg;
+            if (nq > 0) {
+                if (lane < nq) ws.rhs[lane] = row_dot(C, L, ws.act[lane], ws.g);
+                wave_sync();
+                // forward / backward substitution with the maintained factor (uniform, redundant)
+#pragma unroll
+                for (int a = 0; a < NZMAX; ++a)
+                    if (a < nq) {
+                        double acc = ws.rhs[a];
+#pragma unroll
+                        for (int k = 0; k < NZMAX; ++k) if (k < a) acc = fma(-ws.L[a * nz + k], r[k], acc);
+                        r[a] = acc / ws.L[a * nz + a];
+                    }
+#pragma unroll
+                for (int a = NZMAX - 1; a >= 0; --a)
+                    if (a < nq) {
+                        double acc = r[a];
+#pragma unroll
+                        for (int k = 0; k < NZMAX; ++k) if (k > a && k < nq) acc = fma(-ws.L[k * nz + a], r[k], acc);
+                        r[a] = acc / ws.L[a * nz + a];
+                    }
+#pragma unroll
+                for (int a = 0; a < NZMAX; ++a) if (a < nq) delta = fma(-ws.rhs[a], r[a], delta);
+            }
+            // primal direction, component `lane`
+            double zd = 0.0;
+            if (lane < nz) {
+                double acc = ws.g[lane];
+#pragma unroll
+                for (int a = 0; a < NZMAX; ++a) if (a < nq) acc = fma(-ws.Wm[a * nz + lane], r[a], acc);
+                zd = -acc;
+            }
+            const bool dependent = (nq >= nz) || !(delta > QP_TOL_DEP * cg);
+            double t1 = LB_INF, rmax = 0.0;
+            int kdrop = -1;
+#pragma unroll
+            for (int a = 0; a < NZMAX; ++a) if (a < nq && fabs(r[a]) > rmax) rmax = fabs(r[a]);
+#pragma unroll
+            for (int a = 0; a < NZMAX; ++a)
+                if (a < nq && r[a] > QP_TOL_R * rmax) {
+                    double t = u[a] / r[a];
+                    if (t < t1) { t1 = t; kdrop = a; }
+                }
+            const double t2 = dependent ? LB_INF : -sp / delta;
+            const double t = t1 < t2 ? t1 : t2;
+            if (t == LB_INF) { status = LBMPC_ST_QP_INFEASIBLE; goto done; }
+#pragma unroll
+            for (int a = 0; a < NZMAX; ++a) if (a < nq) u[a] = fma(-t, r[a], u[a]);
+#pragma unroll
+            for (int a = 0; a <= NZMAX; ++a) if (a == nq) u[a] += t;
+            if (!dependent) {
+                if (lane < nz) ws.z[lane] = fma(t, zd, ws.z[lane]);
+                sp = fma(t, delta, sp);
+            }
+            wave_sync();
+            if (!dependent && t2 <= t1) {
+                // full step: constraint p joins the active set
+                if (lane < nz) ws.Wm[nq * nz + lane] = ws.g[lane];
+                if (lane == 0) ws.act[nq] = p;
+                wave_sync();
+                chol_append(C, L, ws, nq, p, lane);
+                if (p < nS) { if ((p & 63) == lane) actS |= 1ull << (p >> 6); }
+                else { int h = p - nS; if ((h & 63) == lane) actH |= 1ull << (h >> 6); }
+                nq++;
+                added = true;
+            } else {
+                // drop active constraint kdrop, stay in step 2
+                const int pd = ws.act[kdrop];
+                if (pd < nS) { if ((pd & 63) == lane) actS &= ~(1ull << (pd >> 6)); }
+                else { int h = pd - nS; if ((h & 63) == lane) actH &= ~(1ull << (h >> 6)); }
+                int moved = (lane >= kdrop && lane < nq - 1) ? ws.act[lane + 1] : 0;
+                wave_sync();
+                if (lane >= kdrop && lane < nq - 1) ws.act[lane] = moved;
+                if (lane < nz)
+                    for (int a = kdrop; a < nq - 1; ++a) ws.Wm[a * nz + lane] = ws.Wm[(a + 1) * nz + lane];
+#pragma unroll
+                for (int a = 0; a < NZMAX; ++a) if (a >= kdrop && a < nq) u[a] = u[a + 1];
+                nq--;
+                wave_sync();
+                for (int a = kdrop; a < nq; ++a) chol_append(C, L, ws, a, ws.act[a], lane);
+            }
+        }
+    }
+done:
+    nact_out = nq;
+    iters_out = iters;
+    return status;
+}
+
+// ---- lane-per-trial pieces ----------------------------------------------------------------------
+
+// b_hat = alpha W_b + (1-alpha) W_A v (canonical row order)
+template <int NX>
+__device__ __forceinline__ void w_hat_b(const CtxDev* __restrict__ C, double alpha, const double* v, double* bh) {
+#pragma unroll
+    for (int r = 0; r < 2 * NX; ++r) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) t = fma(C->box.WA[r * NX + k], v[k], t);
+        bh[r] = alpha * C->box.Wb[r] + (1.0 - alpha) * t;
+    }
+}
+
+// Online set update LPforUQ (UQRobustMPC.m:124-139): homothety LP on m = max(b_hat_prev, W_A w_new);
+// (alpha, v) unchanged when w_new is inside W_hat_prev.
+template <int NX>
+__device__ __forceinline__ int uq_update(const CtxDev* __restrict__ C, double& alpha, double* v, const double* w, double* bh) {
+    double mm[2 * NX];
+    bool outside = false;
+    int st = 0;
+    w_hat_b<NX>(C, alpha, v, bh);
+#pragma unroll
+    for (int r = 0; r < 2 * NX; ++r) {
+        double hw = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) hw = fma(C->box.WA[r * NX + k], w[k], hw);
+        mm[r] = bh[r];
+        if (hw > bh[r]) { mm[r] = hw; outside = true; }
+    }
+    if (outside) {
+        uint32_t mask;
+        st = homothety_box<NX>(&C->box, mm, alpha, v, mask);
+        w_hat_b<NX>(C, alpha, v, bh);
+    }
+    return st;
+}
+
+// q = (1-alpha) T v - x ; returns min_r (1 - h_k[r]) and its first index (h_k closed form :80-84)
+template <int NX>
+__device__ __forceinline__ void tighten(const CtxDev* __restrict__ C, double alpha, const double* v, const double* x,
+                                        double* q, double& min_omh, int& arg_omh) {
+    const double beta = 1.0 - alpha;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) acc = fma(C->T[i * NX + k], v[k], acc);
+        q[i] = beta * acc - x[i];
+    }
+    min_omh = LB_INF; arg_omh = 0;
+    for (int r = 0; r < C->nc; ++r) {
+        double g = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) g = fma(C->FcT[r * NX + k], v[k], g);
+        double omh = 1.0 - (alpha * C->hs[r] + beta * g);
+        if (omh < min_omh) { min_omh = omh; arg_omh = r; }
+    }
+}
+
+template <int NX>
+__device__ __forceinline__ double hk_value(const CtxDev* __restrict__ C, double alpha, const double* v, int r) {
+    double g = 0.0;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) g = fma(C->FcT[r * NX + k], v[k], g);
+    return alpha * C->hs[r] + (1.0 - alpha) * g;
+}
+
+// First pass at z = 0 for the T trials of this lane: slack_j = alpha S_b[j] + S_A[j,:].q for the S rows
+// (LDS broadcast of the row), and 1-h_k[r] for the first block of H rows.
+template <int NX, int T>
+__device__ __forceinline__ void first_pass(const CtxDev* __restrict__ C, const LdsView& L, const double* alpha,
+                                           const double (*q)[NX], const double* min_omh, const int* arg_omh,
+                                           double* best, int* bidx) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) { best[t] = -QP_TOL_VIOL; bidx[t] = -1; }
+    const int nS = C->nS, RL = C->RL;
+    const double* row = L.Srow;
+    for (int j = 0; j < nS; ++j, row += RL) {
+        const double sb = row[0];
+        double a[NX];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) a[k] = row[1 + k];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            double acc = alpha[t] * sb;
+#pragma unroll
+            for (int k = 0; k < NX; ++k) acc = fma(a[k], q[t][k], acc);
+            if (acc < best[t]) { best[t] = acc; bidx[t] = j; }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+        if (min_omh[t] < best[t]) { best[t] = min_omh[t]; bidx[t] = nS + arg_omh[t]; }
+}
+
+__device__ __forceinline__ void stage_constants(const CtxDev* __restrict__ C, double* lds) {
+    const int nS_RL = C->nS * C->RL, nH_nzp = C->nH * C->nzp, nzz = C->nz * C->nz;
+    for (int i = threadIdx.x; i < nS_RL; i += blockDim.x) lds[i] = C->Srow[i];
+    for (int i = threadIdx.x; i < nH_nzp; i += blockDim.x) lds[nS_RL + i] = C->Hm[i];
+    for (int i = threadIdx.x; i < nzz; i += blockDim.x) lds[nS_RL + nH_nzp + i] = C->Ginv[i];
+    __syncthreads();
+}
+
+// Solve the QPs of the lanes flagged in `need` one after the other, cooperatively.
+// Owner lane receives: z_head[0..NX) = s0, z_u[0..nu) = c(1:nu), status, iters.
+template <int NX>
+__device__ __forceinline__ void solve_flagged(const CtxDev* __restrict__ C, const LdsView& L, const WsView& ws,
+                                              bool need, double alpha, const double* v, const double* q, int p0,
+                                              double sp0, double* s0, double* c0, int& status, int& iters,
+                                              int* nact_out, int* act_out /* NZMAX, sorted, or null */,
+                                              double* c_full /* nz-NX or null */) {
+    const int lane = lane_id();
+    uint64_t mask = __builtin_amdgcn_ballot_w64(need);
+    while (mask) {
+        const int src = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        double qa[NX];
+        const double a_u = readlane_f64(alpha, src);
+#pragma unroll
+        for (int k = 0; k < NX; ++k) qa[k] = readlane_f64(q[k], src);
+        const int p_u = __builtin_amdgcn_readlane(p0, src);
+        const double sp_u = readlane_f64(sp0, src);
+        if (lane == src)
+            for (int r = 0; r < C->nc; ++r) ws.omh[r] = 1.0 - hk_value<NX>(C, alpha, v, r);
+        wave_sync();
+        int nact = 0, it = 0;
+        const int st = coop_qp_solve<NX>(C, L, ws, a_u, qa, p_u, sp_u, nact, it);
+        wave_sync();
+        if (lane == src) {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) s0[k] = ws.z[k];
+#pragma unroll
+            for (int j = 0; j < LBMPC_MAX_NU; ++j) if (j < C->nu) c0[j] = ws.z[NX + j];
+            status = st > status ? st : status;
+            iters += it;
+            if (nact_out) *nact_out = nact;
+            if (act_out) {
+                for (int a = 0; a < NZMAX; ++a) act_out[a] = -1;
+                for (int a = 0; a < nact; ++a) {  // ascending insertion
+                    int val = ws.act[a], pos = a;
+                    while (pos > 0 && act_out[pos - 1] > val) { act_out[pos] = act_out[pos - 1]; --pos; }
+                    act_out[pos] = val;
+                }
+            }
+            if (c_full) for (int k = NX; k < C->nz; ++k) c_full[k - NX] = ws.z[k];
+        }
+        wave_sync();
+    }
+}
+
+// ---- single-step kernel (lbmpc_uqmpc_step): lane per problem -------------------------------------
+struct StepIO {
+    const double *x, *alpha_prev, *v_prev, *w_new;
+    double *s0, *c, *u, *alpha, *v, *hk, *Sb_hat, *Wb_hat;
+    int *status, *n_active, *active_set, *qp_iters;
+};
+
+template <int NX>
+__global__ __launch_bounds__(256) void uqmpc_step_kernel(const CtxDev* __restrict__ C, int64_t batch, int uq, StepIO io) {
+    extern __shared__ double lds[];
+    stage_constants(C, lds);
+    LdsView L;
+    L.Srow = lds; L.Hm = lds + C->nS * C->RL; L.Ginv = L.Hm + C->nH * C->nzp;
+    const int wave = threadIdx.x / LB_WAVE, nwaves = blockDim.x / LB_WAVE, lane = lane_id();
+    const int nz = C->nz, ncv = nz - NX;
+    WsView ws = ws_view(lds + C->nS * C->RL + C->nH * C->nzp + nz * nz + wave * ws_doubles(nz), nz);
+    for (int64_t base = ((int64_t)blockIdx.x * nwaves + wave) * LB_WAVE; base < batch;
+         base += (int64_t)gridDim.x * nwaves * LB_WAVE) {
+        const int64_t b = base + lane;
+        const bool valid = b < batch;
+        const int64_t bb = valid ? b : batch - 1;
+        double x[NX], v[NX], w[NX], q[1][NX], bh[2 * NX], alpha[1], momh[1], best[1];
+        int aomh[1], bidx[1], status = 0, iters = 0, nact = 0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) { x[k] = io.x[bb * NX + k]; v[k] = io.v_prev[bb * NX + k]; w[k] = (uq && io.w_new) ? io.w_new[bb * NX + k] : 0.0; }
+        alpha[0] = io.alpha_prev[bb];
+        if (uq) status = uq_update<NX>(C, alpha[0], v, w, bh);
+        else w_hat_b<NX>(C, alpha[0], v, bh);
+        tighten<NX>(C, alpha[0], v, x, q[0], momh[0], aomh[0]);
+        first_pass<NX, 1>(C, L, alpha, q, momh, aomh, best, bidx);
+        double s0[NX], c0[LBMPC_MAX_NU];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) s0[k] = 0.0;
+#pragma unroll
+        for (int j = 0; j < LBMPC_MAX_NU; ++j) c0[j] = 0.0;
+        int act_sorted[NZMAX];
+        double* cdst = (valid && io.c) ? io.c + b * ncv : nullptr;
+        if (cdst) for (int k = 0; k < ncv; ++k) cdst[k] = 0.0;
+        if (valid && io.active_set) for (int a = 0; a < NZMAX; ++a) io.active_set[b * NZMAX + a] = -1;
+        solve_flagged<NX>(C, L, ws, valid && bidx[0] >= 0, alpha[0], v, q[0], bidx[0], best[0], s0, c0, status, iters,
+                          &nact, (valid && io.active_set) ? io.active_set + b * NZMAX : nullptr, cdst);
+        (void)act_sorted;
+        if (!valid) continue;
+        if (io.s0) for (int k = 0; k < NX; ++k) io.s0[b * NX + k] = s0[k];
+        if (io.u)
+            for (int j = 0; j < C->nu; ++j) {  // u = K x + c(1:nu)   (UQRobustMPC.m:90)
+                double acc = 0.0;
+#pragma unroll
+                for (int jj = 0; jj < LBMPC_MAX_NU; ++jj) if (jj == j) acc = c0[jj];
+#pragma unroll
+                for (int k = 0; k < NX; ++k) acc = fma(C->K[j * NX + k], x[k], acc);
+                io.u[b * C->nu + j] = acc;
+            }
+        if (io.alpha) io.alpha[b] = alpha[0];
+        if (io.v) for (int k = 0; k < NX; ++k) io.v[b * NX + k] = v[k];
+        if (io.hk) for (int r = 0; r < C->nc; ++r) io.hk[b * C->nc + r] = hk_value<NX>(C, alpha[0], v, r);
+        if (io.Wb_hat)
+#pragma unroll
+            for (int r = 0; r < 2 * NX; ++r) io.Wb_hat[b * 2 * NX + C->box.perm[r]] = bh[r];
+        if (io.Sb_hat) {  // S_hat = alpha S + (1-alpha) T v   (UQRobustMPC.m:76)
+            double Tv[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < NX; ++k) acc = fma(C->T[i * NX + k], v[k], acc);
+                Tv[i] = acc;
+            }
+            for (int j = 0; j < C->nS; ++j) {
+                const double* row = L.Srow + j * C->RL;
+                double t = 0.0;
+#pragma unroll
+                for (int k = 0; k < NX; ++k) t = fma(row[1 + k], Tv[k], t);
+                io.Sb_hat[b * C->nS + j] = alpha[0] * row[0] + (1.0 - alpha[0]) * t;
+            }
+        }
+        if (io.status) io.status[b] = status;
+        if (io.n_active) io.n_active[b] = nact;
+        if (io.qp_iters) io.qp_iters[b] = iters;
+    }
+}
+
+// ---- closed-loop Monte-Carlo kernel ---------------------------------------------------------------
+struct McArgs {
+    int64_t trials, trial0;
+    int steps, card_I0;
+    uint64_t seed;
+    double x0[LBMPC_MAX_NX];
+    double acc_bound, distance_error;
+    int traj_trials, sampler_max_attempts;
+    lbmpc_mc_out out;
+};
+
+template <int NX, int T>
+__global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, SamplerDev smp, McArgs a) {
+    extern __shared__ double lds[];
+    stage_constants(C, lds);
+    LdsView L;
+    L.Srow = lds; L.Hm = lds + C->nS * C->RL; L.Ginv = L.Hm + C->nH * C->nzp;
+    const int wave = threadIdx.x / LB_WAVE, nwaves = blockDim.x / LB_WAVE, lane = lane_id();
+    const int nz = C->nz, nu = C->nu, K = a.steps;
+    WsView ws = ws_view(lds + C->nS * C->RL + C->nH * C->nzp + nz * nz + wave * ws_doubles(nz), nz);
+    const SamplerDev* S = &smp;
+    for (int64_t base = ((int64_t)blockIdx.x * nwaves + wave) * (LB_WAVE * T); base < a.trials;
+         base += (int64_t)gridDim.x * nwaves * (LB_WAVE * T)) {
+        int64_t tl[T];      // local trial index
+        uint64_t tid[T];    // global id = RNG stream key
+        bool valid[T];
+        double x[T][NX], wst[T][NX], v[T][NX], alpha[T];
+        int status[T], infeasible[T], iters[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int64_t l = base + t * LB_WAVE + lane;
+            valid[t] = l < a.trials;
+            tl[t] = valid[t] ? l : a.trials - 1;
+            tid[t] = (uint64_t)(a.trial0 + tl[t]);
+            status[t] = 0; infeasible[t] = 0; iters[t] = 0;
+            // initial set learning: InitialSetComputation.solve (:48-59), card_I0 samples
+            double m[2 * NX];
+#pragma unroll
+            for (int r = 0; r < 2 * NX; ++r) m[r] = -LB_INF;
+            for (int i = 0; i < a.card_I0; ++i) {
+                double w[NX];
+                if (sample_w_I0<NX>(S, a.seed, tid[t], (uint32_t)i, 100, w)) status[t] = LBMPC_ST_SAMPLER_CAP;
+#pragma unroll
+                for (int r = 0; r < 2 * NX; ++r) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) acc = fma(C->box.WA[r * NX + k], w[k], acc);
+                    m[r] = acc > m[r] ? acc : m[r];
+                }
+            }
+            uint32_t mask;
+            int st = homothety_box<NX>(&C->box, m, alpha[t], v[t], mask);
+            status[t] = st > status[t] ? st : status[t];
+#pragma unroll
+            for (int k = 0; k < NX; ++k) {
+                x[t][k] = a.x0[k]; wst[t][k] = 0.0;
+                if (x[t][k] > a.distance_error || x[t][k] < -a.distance_error) infeasible[t] = 1;
+            }
+            if (valid[t] && a.out.alpha0) a.out.alpha0[tl[t]] = alpha[t];
+            if (valid[t] && tl[t] < a.traj_trials) {
+                if (a.out.traj_x) for (int k = 0; k < NX; ++k) a.out.traj_x[(tl[t] * (K + 1)) * NX + k] = x[t][k];
+                if (a.out.traj_alpha) a.out.traj_alpha[tl[t] * (K + 1)] = alpha[t];
+            }
+        }
+        for (int k = 0; k < K; ++k) {
+            double q[T][NX], xi_lv[T][NX], Bul[T][NX], momh[T], best[T];
+            int aomh[T], bidx[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                // LVModeling first (Case_3...:58; ModelingCar.m:42-43)
+                if (sample_polytope<NX>(S->LV_A, S->LV_b, S->nLV, S->LV_lo, S->LV_hi, a.seed, tid[t], (uint32_t)k, P_ST_LV, a.sampler_max_attempts, xi_lv[t]))
+                    status[t] = status[t] > LBMPC_ST_SAMPLER_CAP ? status[t] : LBMPC_ST_SAMPLER_CAP;
+                sample_Bu_lv<NX>(S, a.seed, tid[t], (uint32_t)k, P_ST_U, Bul[t]);
+                double bh[2 * NX];
+                int st = uq_update<NX>(C, alpha[t], v[t], wst[t], bh);  // w_new = 0 at k = 0 (Case_3...:62-65)
+                status[t] = st > status[t] ? st : status[t];
+                tighten<NX>(C, alpha[t], v[t], x[t], q[t], momh[t], aomh[t]);
+            }
+            first_pass<NX, T>(C, L, alpha, q, momh, aomh, best, bidx);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                double s0[NX], c0[LBMPC_MAX_NU], u[LBMPC_MAX_NU];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) s0[i] = 0.0;
+#pragma unroll
+                for (int j = 0; j < LBMPC_MAX_NU; ++j) c0[j] = 0.0;
+                solve_flagged<NX>(C, L, ws, valid[t] && bidx[t] >= 0, alpha[t], v[t], q[t], bidx[t], best[t], s0, c0,
+                                  status[t], iters[t], nullptr, nullptr, nullptr);
+                // u = K x + c(1:nu); EVModeling (ModelingCar.m:36-37); relative dynamics
+                double xi_ev[NX], Ax[NX], Bu[NX], xn[NX];
+#pragma unroll
+                for (int j = 0; j < LBMPC_MAX_NU; ++j) {
+                    u[j] = 0.0;
+                    if (j < nu) {
+                        double acc = c0[j];
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) acc = fma(C->K[j * NX + i], x[t][i], acc);
+                        u[j] = acc;
+                        if (acc > a.acc_bound || acc < -a.acc_bound) infeasible[t] = 1;
+                    }
+                }
+                if (sample_polytope<NX>(S->EV_A, S->EV_b, S->nEV, S->EV_lo, S->EV_hi, a.seed, tid[t], (uint32_t)k, P_ST_EV, a.sampler_max_attempts, xi_ev))
+                    status[t] = status[t] > LBMPC_ST_SAMPLER_CAP ? status[t] : LBMPC_ST_SAMPLER_CAP;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    double acc = 0.0, bcc = 0.0;
+#pragma unroll
+                    for (int kk = 0; kk < NX; ++kk) acc = fma(C->A[i * NX + kk], x[t][kk], acc);
+#pragma unroll
+                    for (int j = 0; j < LBMPC_MAX_NU; ++j) if (j < nu) bcc = fma(C->B[i * nu + j], u[j], bcc);
+                    Ax[i] = acc; Bu[i] = bcc;
+                    xn[i] = ((Ax[i] + Bu[i]) + xi_ev[i]) - (xi_lv[t][i] + Bul[t][i]);
+                }
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    wst[t][i] = (xn[i] - Ax[i]) - Bu[i];  // w_new of the next step (Case_3...:67)
+                    x[t][i] = xn[i];
+                    if (xn[i] > a.distance_error || xn[i] < -a.distance_error) infeasible[t] = 1;
+                }
+                if (valid[t] && tl[t] < a.traj_trials) {
+                    if (a.out.traj_x) for (int i = 0; i < NX; ++i) a.out.traj_x[(tl[t] * (K + 1) + k + 1) * NX + i] = x[t][i];
+                    if (a.out.traj_u) for (int j = 0; j < nu; ++j) {
+                        double uj = 0.0;
+#pragma unroll
+                        for (int jj = 0; jj < LBMPC_MAX_NU; ++jj) if (jj == j) uj = u[jj];
+                        a.out.traj_u[(tl[t] * K + k) * nu + j] = uj;
+                    }
+                    if (a.out.traj_alpha) a.out.traj_alpha[tl[t] * (K + 1) + k + 1] = alpha[t];
+                    if (a.out.traj_s0) for (int i = 0; i < NX; ++i) a.out.traj_s0[(tl[t] * K + k) * NX + i] = s0[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if (!valid[t]) continue;
+            const int64_t l = tl[t];
+            if (a.out.infeasible) a.out.infeasible[l] = infeasible[t];
+            if (a.out.status) a.out.status[l] = status[t];
+            if (a.out.qp_iters) a.out.qp_iters[l] = iters[t];
+            if (a.out.alpha_final) a.out.alpha_final[l] = alpha[t];
+            if (a.out.v_final) for (int i = 0; i < NX; ++i) a.out.v_final[l * NX + i] = v[t][i];
+            if (a.out.x_final) for (int i = 0; i < NX; ++i) a.out.x_final[l * NX + i] = x[t][i];
+        }
+    }
+}
+
+// ---- host: context ----------------------------------------------------------------------------------
+static bool invert_gj(int n, const double* M /* row-major */, double* Minv) {
+    std::vector<double> a((size_t)n * 2 * n);
+    const int w = 2 * n;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) { a[i * w + j] = M[i * n + j]; a[i * w + n + j] = (i == j) ? 1.0 : 0.0; }
+    for (int c = 0; c < n; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < n; ++r) if (std::fabs(a[r * w + c]) > std::fabs(a[piv * w + c])) piv = r;
+        if (std::fabs(a[piv * w + c]) < 1e-300) return false;
+        if (piv != c) for (int k = 0; k < w; ++k) std::swap(a[c * w + k], a[piv * w + k]);
+        const double d = a[c * w + c];
+        for (int k = 0; k < w; ++k) a[c * w + k] /= d;
+        for (int r = 0; r < n; ++r) {
+            if (r == c) continue;
+            const double f = a[r * w + c];
+            if (f != 0.0) for (int k = 0; k < w; ++k) a[r * w + k] -= f * a[c * w + k];
+        }
+    }
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) Minv[i * n + j] = a[i * w + n + j];
+    return true;
+}
+
+}  // namespace lbmpc
+
+using namespace lbmpc;
+
+#define CMX(M, rows, i, j) ((M)[(size_t)(i) + (size_t)(rows) * (size_t)(j)])
+
+extern "C" void lbmpc_destroy(lbmpc_ctx* c) {
+    if (!c) return;
+    if (c->d) (void)hipFree(c->d);
+    if (c->dS) (void)hipFree(c->dS);
+    if (c->dH) (void)hipFree(c->dH);
+    if (c->dG) (void)hipFree(c->dG);
+    delete c;
+}
+
+extern "C" int lbmpc_uqmpc_create(const lbmpc_params* p, lbmpc_ctx** out) {
+    if (out) *out = nullptr;
+    if (int rc = check_device()) return rc;
+    if (!p || !out) { set_error("lbmpc_uqmpc_create: null argument"); return LBMPC_ERR_ARG; }
+    const double* ptrs[] = {p->A, p->B, p->K, p->Phi, p->Px, p->Pc, p->F, p->G, p->F_bar, p->Psi, p->S_A, p->S_b, p->W_A, p->W_b, p->hs};
+    for (const double* q : ptrs) if (!q) { set_error("lbmpc_uqmpc_create: null field in lbmpc_params"); return LBMPC_ERR_ARG; }
+    const int nx = p->nx, nu = p->nu, N = p->N, nc = p->nc, nz = nx + N * nu, nS = p->nS;
+    if (nx < 1 || nu < 1 || N < 1 || nc < 1 || p->Nu < 0 || nS < 1) { set_error("lbmpc_uqmpc_create: bad size"); return LBMPC_ERR_ARG; }
+    const int nH = nc * (p->Nu + 1);
+    if (nx > LBMPC_MAX_NX || nu > LBMPC_MAX_NU || nz > LBMPC_MAX_NZ || nc > LBMPC_MAX_NC || nS > 4096 || nH > 4096) {
+        set_error("lbmpc_uqmpc_create: limits nx<=%d nu<=%d nx+N*nu<=%d nc<=%d nS<=4096 nc*(Nu+1)<=4096", LBMPC_MAX_NX, LBMPC_MAX_NU, LBMPC_MAX_NZ, LBMPC_MAX_NC);
+        return LBMPC_ERR_DIM;
+    }
+    lbmpc_ctx* c = new lbmpc_ctx();
+    CtxDev& h = c->h;
+    std::memset(&h, 0, sizeof(h));
+    if (int rc = pack_box(p->W_A, p->W_b, p->nW, nx, &h.box)) { delete c; return rc; }
+    h.nx = nx; h.nu = nu; h.N = N; h.nc = nc; h.Nu = p->Nu; h.nS = nS; h.nW = p->nW; h.nz = nz; h.nH = nH;
+    h.RL = (nx + 1) | 1;
+    h.nzp = nz | 1;
+    for (int i = 0; i < nx; ++i) for (int j = 0; j < nx; ++j) h.A[i * nx + j] = CMX(p->A, nx, i, j);
+    for (int i = 0; i < nx; ++i) for (int j = 0; j < nu; ++j) h.B[i * nu + j] = CMX(p->B, nx, i, j);
+    for (int j = 0; j < nu; ++j) for (int k = 0; k < nx; ++k) h.K[j * nx + k] = CMX(p->K, nu, j, k);
+    for (int r = 0; r < nc; ++r) h.hs[r] = p->hs[r];
+    // T = (I - Phi)^-1
+    double ImP[16], T[16];
+    for (int i = 0; i < nx; ++i) for (int j = 0; j < nx; ++j) ImP[i * nx + j] = ((i == j) ? 1.0 : 0.0) - CMX(p->Phi, nx, i, j);
+    if (!invert_gj(nx, ImP, T)) { set_error("lbmpc_uqmpc_create: I - Phi is singular"); delete c; return LBMPC_ERR_ARG; }
+    for (int i = 0; i < nx * nx; ++i) h.T[i] = T[i];
+    // FcT = (F + G K) T
+    for (int r = 0; r < nc; ++r) {
+        double fc[LBMPC_MAX_NX];
+        for (int k = 0; k < nx; ++k) {
+            double acc = CMX(p->F, nc, r, k);
+            for (int j = 0; j < nu; ++j) acc = std::fma(CMX(p->G, nc, r, j), CMX(p->K, nu, j, k), acc);
+            fc[k] = acc;
+        }
+        for (int k = 0; k < nx; ++k) {
+            double acc = 0.0;
+            for (int j = 0; j < nx; ++j) acc = std::fma(fc[j], T[j * nx + k], acc);
+            h.FcT[r * nx + k] = acc;
+        }
+    }
+    // Ginv = (2 blkdiag(Px, Pc))^-1, symmetrised
+    std::vector<double> P2((size_t)nz * nz, 0.0), Ginv((size_t)nz * nz);
+    for (int i = 0; i < nx; ++i) for (int j = 0; j < nx; ++j) P2[i * nz + j] = 2.0 * CMX(p->Px, nx, i, j);
+    const int ncv = N * nu;
+    for (int i = 0; i < ncv; ++i) for (int j = 0; j < ncv; ++j) P2[(nx + i) * nz + nx + j] = 2.0 * CMX(p->Pc, ncv, i, j);
+    if (!invert_gj(nz, P2.data(), Ginv.data())) { set_error("lbmpc_uqmpc_create: cost matrix is singular"); delete c; return LBMPC_ERR_ARG; }
+    for (int i = 0; i < nz; ++i) for (int j = i + 1; j < nz; ++j) { double s = 0.5 * (Ginv[i * nz + j] + Ginv[j * nz + i]); Ginv[i * nz + j] = Ginv[j * nz + i] = s; }
+    // S rows [S_b | S_A | pad]
+    std::vector<double> Srow((size_t)nS * h.RL, 0.0);
+    for (int j = 0; j < nS; ++j) { Srow[(size_t)j * h.RL] = p->S_b[j]; for (int k = 0; k < nx; ++k) Srow[(size_t)j * h.RL + 1 + k] = CMX(p->S_A, nS, j, k); }
+    // H rows: F_bar Psi^i, i = 0..Nu  (UQRobustMPC.m:153-155)
+    std::vector<double> Hm((size_t)nH * h.nzp, 0.0), M((size_t)nc * nz), M2((size_t)nc * nz);
+    for (int r = 0; r < nc; ++r) for (int k = 0; k < nz; ++k) M[r * nz + k] = CMX(p->F_bar, nc, r, k);
+    for (int i = 0; i <= p->Nu; ++i) {
+        for (int r = 0; r < nc; ++r) for (int k = 0; k < nz; ++k) Hm[((size_t)i * nc + r) * h.nzp + k] = M[r * nz + k];
+        for (int r = 0; r < nc; ++r) for (int k = 0; k < nz; ++k) {
+            double acc = 0.0;
+            for (int j = 0; j < nz; ++j) acc = std::fma(M[r * nz + j], CMX(p->Psi, nz, j, k), acc);
+            M2[r * nz + k] = acc;
+        }
+        M.swap(M2);
+    }
+    (void)hipGetDevice(&c->device);
+    auto fail = [&](hipError_t e, const char* what) { set_error("lbmpc_uqmpc_create: %s -> %s", what, hipGetErrorString(e)); lbmpc_destroy(c); return LBMPC_ERR_HIP; };
+    hipError_t e;
+    if ((e = hipMalloc((void**)&c->dS, Srow.size() * 8)) != hipSuccess) return fail(e, "hipMalloc");
+    if ((e = hipMalloc((void**)&c->dH, Hm.size() * 8)) != hipSuccess) return fail(e, "hipMalloc");
+    if ((e = hipMalloc((void**)&c->dG, Ginv.size() * 8)) != hipSuccess) return fail(e, "hipMalloc");
+    if ((e = hipMalloc((void**)&c->d, sizeof(CtxDev))) != hipSuccess) return fail(e, "hipMalloc");
+    if ((e = hipMemcpy(c->dS, Srow.data(), Srow.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
+    if ((e = hipMemcpy(c->dH, Hm.data(), Hm.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
+    if ((e = hipMemcpy(c->dG, Ginv.data(), Ginv.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
+    h.Srow = c->dS; h.Hm = c->dH; h.Ginv = c->dG;
+    if ((e = hipMemcpy(c->d, &h, sizeof(CtxDev), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
+    c->lds_const_bytes = (Srow.size() + Hm.size() + Ginv.size()) * 8;
+    *out = c;
+    return 0;
+}
+
+namespace lbmpc {
+static const size_t LDS_LIMIT = 160 * 1024;
+
+// waves per block so that constants + per-wave workspaces fit in 160 KiB of LDS
+static int pick_waves(const lbmpc_ctx* c, int want) {
+    const size_t wsb = (size_t)ws_doubles(c->h.nz) * 8;
+    int w = want;
+    while (w > 1 && c->lds_const_bytes + (size_t)w * wsb > LDS_LIMIT) w >>= 1;
+    if (c->lds_const_bytes + (size_t)w * wsb > LDS_LIMIT) return 0;
+    return w;
+}
+
+template <class Kern>
+static int allow_lds(Kern k, size_t bytes) {
+    LB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+}  // namespace lbmpc
+
+static int step_dev(lbmpc_ctx* c, int64_t batch, int uq, const StepIO& io, hipStream_t st) {
+    const int waves = pick_waves(c, 4);
+    if (!waves) { set_error("constants (%zu B) do not fit in LDS", c->lds_const_bytes); return LBMPC_ERR_DIM; }
+    const size_t lds = c->lds_const_bytes + (size_t)waves * ws_doubles(c->h.nz) * 8;
+    int64_t blocks = (batch + (int64_t)waves * 64 - 1) / ((int64_t)waves * 64);
+    if (blocks > 1024) blocks = 1024;
+    dim3 grid((unsigned)blocks), blk(waves * 64);
+#define LAUNCH_STEP(NXV)                                                                             \
+    do {                                                                                             \
+        if (int rc = allow_lds(uqmpc_step_kernel<NXV>, lds)) return rc;                              \
+        hipLaunchKernelGGL(uqmpc_step_kernel<NXV>, grid, blk, lds, st, c->d, batch, uq, io);         \
+    } while (0)
+    switch (c->h.nx) {
+        case 1: LAUNCH_STEP(1); break;
+        case 2: LAUNCH_STEP(2); break;
+        case 3: LAUNCH_STEP(3); break;
+        default: LAUNCH_STEP(4); break;
+    }
+#undef LAUNCH_STEP
+    LB_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int lbmpc_uqmpc_step(lbmpc_ctx* c, int64_t batch, int uq_update, const double* x, const double* alpha_prev,
+                                const double* v_prev, const double* w_new, double* s0, double* cc, double* u,
+                                double* alpha, double* v, double* hk, double* Sb_hat, double* Wb_hat, int* status,
+                                int* n_active, int* active_set, int* qp_iters) {
+    if (int rc = check_device()) return rc;
+    if (!c || !x || !alpha_prev || !v_prev || (uq_update && !w_new) || batch < 0) { set_error("lbmpc_uqmpc_step: bad argument"); return LBMPC_ERR_ARG; }
+    if (batch == 0) return 0;
+    const CtxDev& h = c->h;
+    const size_t B = (size_t)batch;
+    const int ncv = h.nz - h.nx;
+    struct Out { void* host; size_t bytes; DevBuf buf; };
+    DevBuf dx, da, dv, dw;
+    LB_HIP(dx.alloc(B * h.nx * 8)); LB_HIP(da.alloc(B * 8)); LB_HIP(dv.alloc(B * h.nx * 8)); LB_HIP(dw.alloc(B * h.nx * 8));
+    LB_HIP(hipMemcpy(dx.p, x, B * h.nx * 8, hipMemcpyHostToDevice));
+    LB_HIP(hipMemcpy(da.p, alpha_prev, B * 8, hipMemcpyHostToDevice));
+    LB_HIP(hipMemcpy(dv.p, v_prev, B * h.nx * 8, hipMemcpyHostToDevice));
+    if (w_new) LB_HIP(hipMemcpy(dw.p, w_new, B * h.nx * 8, hipMemcpyHostToDevice));
+    Out outs[12] = {{s0, B * h.nx * 8, {}}, {cc, B * ncv * 8, {}}, {u, B * h.nu * 8, {}}, {alpha, B * 8, {}},
+                    {v, B * h.nx * 8, {}}, {hk, B * h.nc * 8, {}}, {Sb_hat, B * h.nS * 8, {}}, {Wb_hat, B * h.nW * 8, {}},
+                    {status, B * 4, {}}, {n_active, B * 4, {}}, {active_set, B * NZMAX * 4, {}}, {qp_iters, B * 4, {}}};
+    for (auto& o : outs) if (o.host) LB_HIP(o.buf.alloc(o.bytes));
+    StepIO io;
+    io.x = dx.as<double>(); io.alpha_prev = da.as<double>(); io.v_prev = dv.as<double>(); io.w_new = w_new ? dw.as<double>() : nullptr;
+    io.s0 = outs[0].buf.as<double>(); io.c = outs[1].buf.as<double>(); io.u = outs[2].buf.as<double>();
+    io.alpha = outs[3].buf.as<double>(); io.v = outs[4].buf.as<double>(); io.hk = outs[5].buf.as<double>();
+    io.Sb_hat = outs[6].buf.as<double>(); io.Wb_hat = outs[7].buf.as<double>(); io.status = outs[8].buf.as<int>();
+    io.n_active = outs[9].buf.as<int>(); io.active_set = outs[10].buf.as<int>(); io.qp_iters = outs[11].buf.as<int>();
+    if (int rc = step_dev(c, batch, uq_update, io, nullptr)) return rc;
+    LB_HIP(hipDeviceSynchronize());
+    for (auto& o : outs) if (o.host) LB_HIP(hipMemcpy(o.host, o.buf.p, o.bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lbmpc_mc_cfg* cfg, lbmpc_mc_out* out,
+                                void* stream) {
+    if (int rc = check_device()) return rc;
+    if (!c || !smp || !cfg || !out || !cfg->x0) { set_error("lbmpc_mc_run: null argument"); return LBMPC_ERR_ARG; }
+    if (cfg->trials < 0 || cfg->steps < 0 || cfg->card_I0 < 1 || cfg->sampler_max_attempts < 1 || cfg->traj_trials < 0) { set_error("lbmpc_mc_run: bad configuration"); return LBMPC_ERR_ARG; }
+    SamplerDev sd;
+    if (int rc = pack_sampler(smp, &sd)) return rc;
+    if (sd.nx != c->h.nx || sd.nu != c->h.nu) { set_error("lbmpc_mc_run: sampler dims differ from the controller's"); return LBMPC_ERR_ARG; }
+    if (cfg->trials == 0) return 0;
+    McArgs a;
+    a.trials = cfg->trials; a.trial0 = cfg->trial0; a.steps = cfg->steps; a.card_I0 = cfg->card_I0; a.seed = cfg->seed;
+    for (int k = 0; k < LBMPC_MAX_NX; ++k) a.x0[k] = k < c->h.nx ? cfg->x0[k] : 0.0;
+    a.acc_bound = cfg->acc_bound; a.distance_error = cfg->distance_error;
+    a.traj_trials = cfg->traj_trials; a.sampler_max_attempts = cfg->sampler_max_attempts;
+    a.out = *out;
+    // T = 2 trials per lane once there are enough trials to fill the chip at that width
+    const bool wide = cfg->trials >= (int64_t)256 * 4 * 128;
+    const int waves = pick_waves(c, 8);
+    if (!waves) { set_error("constants (%zu B) do not fit in LDS", c->lds_const_bytes); return LBMPC_ERR_DIM; }
+    const size_t lds = c->lds_const_bytes + (size_t)waves * ws_doubles(c->h.nz) * 8;
+    const int per_block = waves * 64 * (wide ? 2 : 1);
+    int64_t blocks = (cfg->trials + per_block - 1) / per_block;
+    const int64_t resident = 256 * (int64_t)(LDS_LIMIT / lds > 4 ? 4 : (LDS_LIMIT / lds < 1 ? 1 : LDS_LIMIT / lds));
+    if (blocks > resident * 4) blocks = resident * 4;
+    dim3 grid((unsigned)blocks), blk(waves * 64);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_MC(NXV, TV)                                                                      \
+    do {                                                                                        \
+        if (int rc = allow_lds(mc_kernel<NXV, TV>, lds)) return rc;                             \
+        hipLaunchKernelGGL((mc_kernel<NXV, TV>), grid, blk, lds, st, c->d, sd, a);              \
+    } while (0)
+    switch (c->h.nx * 2 + (wide ? 1 : 0)) {
+        case 2: LAUNCH_MC(1, 1); break;
+        case 3: LAUNCH_MC(1, 2); break;
+        case 4: LAUNCH_MC(2, 1); break;
+        case 5: LAUNCH_MC(2, 2); break;
+        case 6: LAUNCH_MC(3, 1); break;
+        case 7: LAUNCH_MC(3, 2); break;
+        case 8: LAUNCH_MC(4, 1); break;
+        default: LAUNCH_MC(4, 2); break;
+    }
+#undef LAUNCH_MC
+    LB_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int lbmpc_mc_run(lbmpc_ctx* c, const lbmpc_sampler* smp, const lbmpc_mc_cfg* cfg, lbmpc_mc_out* out) {
+    if (int rc = check_device()) return rc;
+    if (!c || !cfg || !out) { set_error("lbmpc_mc_run: null argument"); return LBMPC_ERR_ARG; }
+    if (cfg->trials < 0 || cfg->steps < 0 || cfg->traj_trials < 0) { set_error("lbmpc_mc_run: bad configuration"); return LBMPC_ERR_ARG; }
+    const size_t Tn = (size_t)cfg->trials, nx = c->h.nx, nu = c->h.nu, K = (size_t)cfg->steps;
+    const size_t R = (size_t)(cfg->traj_trials < cfg->trials ? cfg->traj_trials : cfg->trials);
+    struct Out { void* host; size_t bytes; DevBuf buf; };
+    Out o[11] = {{out->infeasible, Tn * 4, {}}, {out->status, Tn * 4, {}}, {out->qp_iters, Tn * 4, {}},
+                 {out->alpha_final, Tn * 8, {}}, {out->v_final, Tn * nx * 8, {}}, {out->alpha0, Tn * 8, {}},
+                 {out->x_final, Tn * nx * 8, {}}, {out->traj_x, R * (K + 1) * nx * 8, {}}, {out->traj_u, R * K * nu * 8, {}},
+                 {out->traj_alpha, R * (K + 1) * 8, {}}, {out->traj_s0, R * K * nx * 8, {}}};
+    for (auto& x : o) if (x.host) LB_HIP(x.buf.alloc(x.bytes));
+    lbmpc_mc_out d;
+    d.infeasible = o[0].buf.as<int32_t>(); d.status = o[1].buf.as<int32_t>(); d.qp_iters = o[2].buf.as<int32_t>();
+    d.alpha_final = o[3].buf.as<double>(); d.v_final = o[4].buf.as<double>(); d.alpha0 = o[5].buf.as<double>();
+    d.x_final = o[6].buf.as<double>(); d.traj_x = o[7].buf.as<double>(); d.traj_u = o[8].buf.as<double>();
+    d.traj_alpha = o[9].buf.as<double>(); d.traj_s0 = o[10].buf.as<double>();
+    lbmpc_mc_cfg cf = *cfg;
+    cf.traj_trials = (int32_t)R;
+    if (int rc = lbmpc_mc_run_dev(c, smp, &cf, &d, nullptr)) return rc;
+    LB_HIP(hipDeviceSynchronize());
+    for (auto& x : o) if (x.host) LB_HIP(hipMemcpy(x.host, x.buf.p, x.bytes, hipMemcpyDeviceToHost));
+    return 0;
+}

@@ -14,7 +14,7 @@ c_int_p = C.POINTER(C.c_int)
 c_int32_p = C.POINTER(C.c_int32)
 c_uint32_p = C.POINTER(C.c_uint32)
 
-MAX_NX, MAX_NZ, MAX_NC, MAX_NW, MAX_NXI, MAX_NV, MAX_S = 4, 16, 16, 16, 32, 1024, 64
+MAX_NX, MAX_NZ, MAX_NC, MAX_NW, MAX_NXI, MAX_NV, MAX_S = 4, 16, 16, 16, 16, 1024, 64
 ERR_ARG, ERR_DIM, ERR_HIP, ERR_UNSUPPORTED, ERR_NODEVICE = -1, -2, -3, -4, -5
 ST_OK, ST_QP_INFEASIBLE, ST_LP_INFEASIBLE, ST_ITER_CAP, ST_SAMPLER_CAP = 0, 1, 2, 3, 4
 MS_MAX_LITERAL, MS_SUM_LITERAL, MS_RAKOVIC = 0, 1, 2

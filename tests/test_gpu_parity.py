@@ -1,0 +1,307 @@
+"""GPU parity tests: the HIP library (through the C ABI) against the CPU oracle on the same seeded
+inputs, and against the reference's stored goldens.  Bars (BASELINE.json north_star): flags, statuses,
+active sets, maxima and RNG streams exact; set quantities <= 1e-9 relative; QP primal <= 1e-6."""
+import numpy as np
+import pytest
+
+import fixtures
+import oracle_core
+from lbmpc import _abi
+
+pytestmark = pytest.mark.gpu
+
+SET_RTOL = 1e-9   # (alpha, v), support values, h_k, S_hat.b
+QP_TOL = 1e-6     # s_0, c, u
+
+
+@pytest.fixture(scope="module")
+def core():
+    from lbmpc import core as c
+    c.init(0)
+    return c
+
+
+@pytest.fixture(scope="module")
+def P():
+    return fixtures.params_dict()
+
+
+@pytest.fixture(scope="module")
+def smp(P):
+    return _abi.make_sampler(**fixtures.sampler_args(P))
+
+
+# ---------------------------------------------------------------- subsystem 2
+def test_halfspace_max_golden_results_1(core):
+    """Results_1 sample sets (5 ... 20000 samples) -> maxima bit-exact, alpha vs stored Alpha_ini"""
+    R = fixtures.npz("results_1.npz")
+    WA, Wb = R["W_H"][:, :-1], R["W_H"][:, -1]
+    for i in range(5):
+        S = R[f"Samples_{i}"]
+        m_gpu = core.halfspace_max(WA, S)
+        m_cpu = oracle_core.halfspace_max(WA, S)
+        np.testing.assert_array_equal(m_gpu, m_cpu)
+        a, v, mask, st = core.homothety_lp(WA, Wb, m_gpu)
+        a2, v2, mask2, st2 = oracle_core.homothety_lp(WA, Wb, m_cpu)
+        assert (a, mask, st) == (a2, mask2, st2)
+        np.testing.assert_array_equal(v, v2)
+        assert abs(a - R["Alpha_ini"][i]) < 1e-7
+
+
+@pytest.mark.parametrize("nx,nW,N,batch", [(2, 4, 1, 3), (2, 4, 63, 5), (2, 4, 1000, 7), (2, 4, 20000, 33),
+                                           (3, 6, 777, 9), (4, 8, 4097, 11), (1, 2, 513, 4), (2, 6, 999, 3),
+                                           (4, 5, 300, 2), (3, 6, 200001, 1), (2, 4, 3000000, 1)])
+def test_halfspace_max_shapes(core, nx, nW, N, batch):
+    """ragged sizes, every nx, box and non-box row counts, split-over-waves and one-wave paths: bit-exact"""
+    rng = np.random.default_rng(nx * 1000 + N)
+    WA = rng.normal(size=(nW, nx))
+    S = rng.normal(size=(batch, nx, N))
+    np.testing.assert_array_equal(core.halfspace_max(WA, S), oracle_core.halfspace_max(WA, S))
+
+
+def test_halfspace_max_property_full_size(core, P):
+    """BASELINE config C2 size (N=20000, batch 2048): max over a set == max of maxima over a partition,
+    and planting a known extreme sample moves exactly the rows it should."""
+    rng = np.random.default_rng(7)
+    N, batch = 20000, 1024
+    S = rng.uniform(-0.1, 0.1, size=(batch, 2, N))
+    S[5, :, 12345] = [0.3, -0.15]
+    WA = P["W_A"]
+    m = core.halfspace_max(WA, S)
+    m2 = np.maximum(core.halfspace_max(WA, S[:, :, :7001]), core.halfspace_max(WA, S[:, :, 7001:]))
+    np.testing.assert_array_equal(m, m2)
+    np.testing.assert_array_equal(m[5], oracle_core.halfspace_max(WA, S[5]))
+    assert np.all(m[5] >= WA @ np.array([0.3, -0.15]) - 1e-18)
+
+
+def test_halfspace_max_errors(core, P):
+    with pytest.raises(core.LbmpcError):
+        core.halfspace_max(np.zeros((17, 2)), np.zeros((2, 4)))       # nW beyond limit
+    with pytest.raises(core.LbmpcError):
+        core.halfspace_max(np.zeros((4, 5)), np.zeros((5, 4)))        # nx beyond limit
+    with pytest.raises(core.LbmpcError):
+        core.homothety_lp(np.ones((4, 2)), np.ones(4), np.zeros(4))   # W not an axis-aligned box
+    # a sample outside the prior W: LP infeasible, reported (the reference returns IPOPT garbage)
+    a, v, mask, st = core.homothety_lp(P["W_A"], P["W_b"], P["W_b"] * np.array([1.0, 1.5, 1.0, 1.0]))
+    assert st == _abi.ST_LP_INFEASIBLE and a == 1.0
+
+
+def test_sampler_stream_bit_exact(core, P, smp):
+    """on-device generation of information sets == oracle stream (Philox + rejection), any set offset"""
+    for N, batch, set0 in [(1, 2, 0), (100, 5, 0), (1000, 3, 12345678901), (4099, 2, 7)]:
+        S, m, st = core.sample_information_sets(smp, P["W_A"], N, batch, seed=2, set0=set0)
+        S2, m2, st2 = oracle_core.sample_information_sets(smp, P["W_A"], N, batch, seed=2, set0=set0)
+        np.testing.assert_array_equal(S, S2)
+        np.testing.assert_array_equal(m, m2)
+        np.testing.assert_array_equal(st, st2)
+        # samples lie in W_true = Xi_EV + (-Xi_LV) + (-B U_LV)
+        H = P["W_true_H"]
+        assert (np.einsum("rk,bkn->brn", H[:, :-1], S) <= H[:, -1][None, :, None] + 1e-9).all()
+
+
+def test_case_2_statistics(core, P, smp):
+    """Case_2: vol(W_hat_0) = alpha^nx vol(W) vs card(I_0^w); means agree with Results_2 statistically
+    (reference RNG unseeded) and the GPU equals the oracle exactly."""
+    R = fixtures.npz("results_2.npz")
+    volW = 1.0 * 0.4
+    for idx in (0, 8, 16, 24):
+        N = int(R["N_sam_ini"][idx])
+        _, m, _ = core.sample_information_sets(smp, P["W_A"], N, 256, seed=2, set0=1000 * idx, want_samples=False)
+        a, v, mask, st = core.homothety_lp(P["W_A"], P["W_b"], m)
+        _, m2, _ = oracle_core.sample_information_sets(smp, P["W_A"], N, 256, seed=2, set0=1000 * idx, want_samples=False)
+        a2, v2, _, _ = oracle_core.homothety_lp(P["W_A"], P["W_b"], m2)
+        np.testing.assert_array_equal(a, a2)
+        np.testing.assert_array_equal(v, v2)
+        ref = R["W_Hat_Vol"][idx]
+        mine = a ** 2 * volW
+        assert abs(mine.mean() - ref.mean()) < 4 * ref.std() / np.sqrt(30) + 0.1 * ref.mean()
+
+
+# ---------------------------------------------------------------- subsystem 1
+def test_support_hs_golden(core, P):
+    """hs = max F_Com S.V' (stored in parameters_2x2.mat)"""
+    Fc = P["F"] + P["G"] @ P["K"]
+    h = core.support_batch(np.eye(2), P["S_V"], 1, 0.0, Fc.T)
+    np.testing.assert_allclose(h, P["hs"].ravel(), atol=1.5e-8)
+    np.testing.assert_array_equal(h, oracle_core.support_batch(np.eye(2), P["S_V"], 1, 0.0, Fc.T))
+
+
+@pytest.mark.parametrize("nx,nV,s,nd,tr", [(2, 4, 7, 1000, True), (2, 4, 11, 77, False), (3, 8, 9, 5000, True),
+                                           (4, 16, 10, 100000, True), (4, 16, 30, 4097, True), (1, 2, 5, 300, True),
+                                           (2, 119, 1, 64, True), (4, 16, 8, 3000000, True)])
+def test_support_batch_vs_oracle(core, nx, nV, s, nd, tr):
+    rng = np.random.default_rng(nx + nV + s)
+    A = 0.6 * rng.normal(size=(nx, nx)) / np.sqrt(nx)
+    Vw = rng.uniform(-1, 1, size=(nV, nx))
+    D = rng.normal(size=(nx, nd))
+    D /= np.linalg.norm(D, axis=0)
+    h = core.support_batch(A, Vw, s, 0.05, D, transpose=tr)
+    h2 = oracle_core.support_batch(A, Vw, s, 0.05, D, transpose=tr)
+    np.testing.assert_allclose(h, h2, rtol=SET_RTOL, atol=0)
+    # positive homogeneity and sub-additivity of a support function
+    h3 = core.support_batch(A, Vw, s, 0.05, 2.5 * D[:, :1000], transpose=tr)
+    np.testing.assert_allclose(h3, 2.5 * h[:1000], rtol=1e-12)
+
+
+def test_mrpi_s_alpha(core, P):
+    """(s, alpha) loop of MRPISet.m:27-63; the exact-formula cross-checks of SURVEY.md Appendix B"""
+    Phi, WV, WA, Wb = P["Phi"], P["W_V"], P["W_A"], P["W_b"]
+    D = np.hstack([np.eye(2), -np.eye(2)])
+    for eps, s_ref, a_ref in ((0.1, 7, 0.123623), (0.01, 11, 0.0151979)):
+        s, a, Ms, rc = core.mrpi_s_alpha(Phi, WV, WA, Wb, D, eps, mode=_abi.MS_RAKOVIC)
+        assert rc == 0 and s == s_ref and abs(a - a_ref) < 1e-6
+        assert (s, a, Ms, rc) == oracle_core.mrpi_s_alpha(Phi, WV, WA, Wb, D, eps, mode=_abi.MS_RAKOVIC)
+        Fc = P["F"] + P["G"] @ P["K"]
+        h = core.support_batch(Phi, WV, s, a, Fc.T, transpose=True)
+        ref = {0.1: [0.162328, 1.020390], 0.01: [0.149607, 0.933744]}[eps]
+        np.testing.assert_allclose(h[[0, 2]], ref, atol=2e-6)
+    # golden pin: the upstream parameters.mat hs (2-D tree loop at eps = 0.01) through the HIP path
+    U = fixtures.params_dict("params_upstream.npz")
+    s, a, Ms, rc = core.mrpi_s_alpha(U["Phi"], U["W_V"], U["W_A"], U["W_b"], D, 0.01, mode=_abi.MS_SUM_LITERAL)
+    assert (s, rc) == (13, 0)
+    h = core.support_batch(U["Phi"], U["W_V"], s, a, (U["F"] + U["G"] @ U["K"]).T, transpose=True)
+    np.testing.assert_allclose(h, U["hs"].ravel(), atol=1.5e-8)
+    rng = np.random.default_rng(3)
+    extra = rng.normal(size=(2, 10))
+    D2 = np.hstack([D, extra / np.linalg.norm(extra, axis=0)])
+    for mode in (_abi.MS_MAX_LITERAL, _abi.MS_SUM_LITERAL):
+        assert core.mrpi_s_alpha(Phi, WV, WA, Wb, D2, 0.1, mode=mode) == oracle_core.mrpi_s_alpha(Phi, WV, WA, Wb, D2, 0.1, mode=mode)
+
+
+# ---------------------------------------------------------------- subsystem 3
+def compare_steps(g, o):
+    np.testing.assert_array_equal(g["status"], o["status"])
+    np.testing.assert_array_equal(g["n_active"], o["n_active"])
+    np.testing.assert_array_equal(g["active_set"], o["active_set"])
+    np.testing.assert_array_equal(g["qp_iters"], o["qp_iters"])
+    for k in ("alpha", "v", "hk", "Sb_hat", "Wb_hat"):
+        np.testing.assert_allclose(g[k], o[k], rtol=SET_RTOL, atol=1e-15, err_msg=k)
+    ok = o["status"] == 0
+    for k in ("s0", "c", "u"):
+        np.testing.assert_allclose(g[k][ok], o[k][ok], rtol=QP_TOL, atol=QP_TOL, err_msg=k)
+
+
+def test_step_vs_oracle_random(core, P):
+    ctx, octx = core.Context(P), oracle_core.Context(P)
+    rng = np.random.default_rng(0)
+    V = P["F_N_RMPC_V"]
+    B = 500
+    lam = rng.dirichlet(np.ones(3), size=B)
+    X = np.einsum("bi,bik->bk", lam, V[rng.integers(0, len(V), (B, 3))]) * rng.uniform(0.1, 1.05, (B, 1))
+    X[-3:] = [[40, 10], [-30, 5], [0, 0]]  # infeasible / infeasible / origin
+    alpha = rng.uniform(0.05, 1.0, B)
+    v = rng.uniform(-0.05, 0.05, (B, 2))
+    w = rng.uniform(-0.2, 0.2, (B, 2)) * np.array([1.0, 0.4])
+    for uq in (False, True):
+        g = ctx.step(X.T, alpha, v.T, w.T, uq_update=uq)
+        o = octx.step(X.T, alpha, v.T, w.T, uq_update=uq)
+        compare_steps(g, o)
+        assert (o["n_active"] > 0).sum() > 100 and (o["status"] == _abi.ST_QP_INFEASIBLE).sum() >= 2
+    ctx.close(); octx.close()
+
+
+@pytest.mark.parametrize("tag", ["small", "large"])
+def test_step_golden_results_3(core, P, tag):
+    """the 50 stored steps of Case_3 through the HIP path: h_k, S_hat.b, (s_0, u_k), alpha_k"""
+    from test_oracle_golden import recover_alpha_v
+    from scipy.optimize import linprog
+    R = fixtures.npz(f"results_3_{tag}.npz")
+    WA, Wb = P["W_A"], P["W_b"]
+    T = np.linalg.inv(np.eye(2) - P["Phi"])
+    av = [recover_alpha_v(WA, Wb, R["W_Hat_H"][k][:, -1]) for k in range(50)]
+    a0, v0 = av[0]
+    SA = R["S_Hat_H"][0][:, :-1]
+    Sb = (R["S_Hat_H"][0][:, -1] - (1 - a0) * SA @ T @ v0) / a0
+    Fc = P["F"] + P["G"] @ P["K"]
+    hs = np.array([-linprog(-Fc[i], A_ub=SA, b_ub=Sb, bounds=[(None, None)] * 2, method="highs").fun for i in range(4)])
+    d = dict(P)
+    d.update(S_A=SA, S_b=Sb, hs=hs)
+    ctx, octx = core.Context(d), oracle_core.Context(d)
+    X, U, S0, HS = R["State_RM"], R["Control_EV"], R["Nominal_RM_State"], R["Hs"]
+    alphas = np.array([a for a, _ in av])
+    vs = np.array([v for _, v in av])
+    g = ctx.step(X[:, :50], alphas, vs.T, None, uq_update=False)
+    o = octx.step(X[:, :50], alphas, vs.T, None, uq_update=False)
+    compare_steps(g, o)
+    np.testing.assert_allclose(g["hk"], HS.T, atol=1.5e-8)
+    np.testing.assert_allclose(g["Sb_hat"], R["S_Hat_H"][:, :, -1], atol=2e-9)
+    np.testing.assert_allclose(g["s0"], S0[:, :50].T, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(g["u"][:, 0], U[0], rtol=1e-6, atol=1e-6)
+    Wn = X[:, 1:50] - P["A"] @ X[:, :49] - P["B"] @ U[:, :49]
+    g2 = ctx.step(X[:, 1:50], alphas[:49], vs[:49].T, Wn, uq_update=True)
+    np.testing.assert_allclose(g2["alpha"], alphas[1:], atol=1e-7)
+    ctx.close(); octx.close()
+
+
+def test_nominal_rmpc(core, P):
+    """NominalRobustMPC.solve == the same QP with alpha = 1, v = 0, no update (parity unpinned vs reference:
+    no stored output; oracle only)"""
+    ctx, octx = core.Context(P), oracle_core.Context(P)
+    rng = np.random.default_rng(5)
+    X = rng.uniform(-1, 1, (2, 64)) * np.array([[12.0], [5.0]])
+    g = ctx.step(X, np.ones(64), np.zeros((2, 64)), None, uq_update=False)
+    o = octx.step(X, np.ones(64), np.zeros((2, 64)), None, uq_update=False)
+    compare_steps(g, o)
+    np.testing.assert_allclose(g["hk"], np.tile(P["hs"].ravel(), (64, 1)), rtol=1e-15)
+    ctx.close(); octx.close()
+
+
+def compare_mc(g, o):
+    for k in ("infeasible", "status", "qp_iters"):
+        np.testing.assert_array_equal(g[k], o[k], err_msg=k)
+    for k in ("alpha0", "alpha_final", "v_final", "traj_alpha"):
+        np.testing.assert_allclose(g[k], o[k], rtol=SET_RTOL, atol=1e-15, err_msg=k)
+    for k in ("x_final", "traj_x", "traj_u", "traj_s0"):
+        np.testing.assert_allclose(g[k], o[k], rtol=QP_TOL, atol=QP_TOL, err_msg=k)
+
+
+def test_mc_case_3_trajectory(core, P, smp):
+    """Case_3: K_N = 50 from x_RM_0 = [-12; 5], card(I0) = 100; whole trajectories vs oracle"""
+    ctx, octx = core.Context(P), oracle_core.Context(P)
+    kw = dict(trials=70, steps=50, card_I0=100, seed=1, x0=[-12.0, 5.0], acc_bound=2.0, distance_error=15.0, traj_trials=70)
+    g, o = ctx.mc_run(smp, **kw), octx.mc_run(smp, **kw)
+    compare_mc(g, o)
+    assert o["qp_iters"].min() > 10 and o["infeasible"].sum() == 0
+    ctx.close(); octx.close()
+
+
+def test_mc_case_5_feasibility_flags(core, P, smp):
+    """Case_5: near-boundary initial state, 20 steps; Infeasible_Index exact vs oracle, rate vs Results_5"""
+    R = fixtures.npz("results_5.npz")
+    ctx, octx = core.Context(P), oracle_core.Context(P)
+    for n, trials in ((10, 2000), (100, 300)):
+        kw = dict(trials=trials, steps=20, card_I0=n, seed=5, x0=R[f"x_RM_0_{n}"], acc_bound=2.0, distance_error=15.0,
+                  traj_trials=5)
+        g, o = ctx.mc_run(smp, **kw), octx.mc_run(smp, **kw)
+        compare_mc(g, o)
+        rate, ref = g["infeasible"].mean(), R[f"Infeasible_Index_{n}"].mean()
+        if n == 10:
+            assert 0.02 < rate < 0.40 and ref == 0.16   # statistical: reference RNG is unseeded
+        else:
+            assert rate <= 0.02 and ref == 0.0
+    ctx.close(); octx.close()
+
+
+def test_mc_sharding_invariance(core, P, smp):
+    """trial-sharded runs (trial0 offsets, as the multi-GPU driver issues them) reproduce the unsharded run bitwise"""
+    ctx = core.Context(P)
+    kw = dict(steps=12, card_I0=10, seed=9, x0=[-12.0, 5.0], acc_bound=2.0, distance_error=15.0)
+    full = ctx.mc_run(smp, trials=300, **kw)
+    a = ctx.mc_run(smp, trials=130, trial0=0, **kw)
+    b = ctx.mc_run(smp, trials=170, trial0=130, **kw)
+    for k in ("infeasible", "status", "qp_iters", "alpha_final", "v_final", "x_final"):
+        np.testing.assert_array_equal(full[k], np.concatenate([a[k], b[k]]), err_msg=k)
+    ctx.close()
+
+
+def test_mc_wide_path_matches_narrow(core, P, smp):
+    """>= 131072 trials switches to 2 trials per lane; its first trials must equal a small (1 per lane) run"""
+    ctx = core.Context(P)
+    kw = dict(steps=6, card_I0=10, seed=4, x0=[-12.0, 5.0], acc_bound=2.0, distance_error=15.0)
+    big = ctx.mc_run(smp, trials=131072 + 77, **kw)
+    small = ctx.mc_run(smp, trials=500, **kw)
+    tail = ctx.mc_run(smp, trials=77, trial0=131072, **kw)
+    for k in ("infeasible", "status", "qp_iters", "alpha_final", "v_final", "x_final"):
+        np.testing.assert_array_equal(big[k][:500], small[k], err_msg=k)
+        np.testing.assert_array_equal(big[k][131072:], tail[k], err_msg=k)
+    ctx.close()

@@ -270,3 +270,18 @@ def test_qp_kkt_random_states(orc, P):
     o = step(orc, ctx, d, 0, np.array([40.0, 10.0]), 0.5, np.zeros(2), np.zeros(2))
     assert o["status"] == _abi.ST_QP_INFEASIBLE
     orc.orc_destroy(ctx)
+
+
+def test_upstream_hs_pins_s_alpha_and_support_sum():
+    """parameters.mat (the upstream 2-D parameter set) stores hs = h_S((F+GK)_i) for the S built by
+    Functions/MRPISet.m at epsilon = 0.01.  The 2-D (s, alpha) loop (:8-17, mode SUM_LITERAL) gives s = 13,
+    alpha = 0.0053213, and the Minkowski-sum support (1-alpha)^-1 sum_{t<s} h_W((Phi^t)' d) reproduces the
+    stored hs to IPOPT accuracy: a golden pin of subsystem 1 (support sweep + (s, alpha) search)."""
+    import oracle_core
+    U = fixtures.params_dict("params_upstream.npz")
+    D = np.hstack([np.eye(2), -np.eye(2)])
+    Fc = U["F"] + U["G"] @ U["K"]
+    s, a, Ms, rc = oracle_core.mrpi_s_alpha(U["Phi"], U["W_V"], U["W_A"], U["W_b"], D, 0.01, mode=_abi.MS_SUM_LITERAL)
+    assert (s, rc) == (13, 0) and abs(a - 0.005321295948) < 1e-11
+    h = oracle_core.support_batch(U["Phi"], U["W_V"], s, a, Fc.T, transpose=True)
+    np.testing.assert_allclose(h, U["hs"].ravel(), atol=1.5e-8)
