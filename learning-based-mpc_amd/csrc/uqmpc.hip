@@ -105,7 +105,7 @@ __device__ __forceinline__ void chol_append(const CtxDev* __restrict__ C, const 
             double acc = row_dot(C, L, pa, ws.Wm + b * nz);
 #pragma unroll
             for (int k = 0; k < NZMAX; ++k)
-                if (k < b) acc = fma(-Lrow[k], ws.L[b * nz + k], acc);
+                if (k < b) acc = fma(-Lrow[k], (b < a) ? ws.L[b * nz + k] : Lrow[k], acc);
             if (b < a) Lrow[b] = acc / ws.L[b * nz + b];
             else Lrow[b] = sqrt(acc > 0.0 ? acc : 0.0);
         }
@@ -183,7 +183,6 @@ __device__ int coop_qp_solve(const CtxDev* __restrict__ C, const LdsView& L, con
         }
         wave_sync();
         const double cg = row_dot(C, L, p, ws.g);
-        u[nq < NZMAX ? nq : NZMAX] = 0.0;  // u[nq] = 0 (static indexing below)
 #pragma unroll
         for (int a = 0; a <= NZMAX; ++a) if (a == nq) u[a] = 0.0;
         // Step 2
@@ -238,6 +237,9 @@ __device__ int coop_qp_solve(const CtxDev* __restrict__ C, const LdsView& L, con
                 }
             const double t2 = dependent ? LB_INF : -sp / delta;
             const double t = t1 < t2 ? t1 : t2;
+#ifdef LBMPC_TRACE
+            if (lane == 0) printf("GPU it=%d p=%d sp=%.17g nq=%d cg=%.17g delta=%.17g t1=%.17g t2=%.17g kdrop=%d dep=%d r0=%.17g u0=%.17g\n", iters, p, sp, nq, cg, delta, t1, t2, kdrop, (int)dependent, r[0], u[0]);
+#endif
             if (t == LB_INF) { status = LBMPC_ST_QP_INFEASIBLE; goto done; }
 #pragma unroll
             for (int a = 0; a < NZMAX; ++a) if (a < nq) u[a] = fma(-t, r[a], u[a]);

@@ -19,6 +19,7 @@
  */
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -653,6 +654,9 @@ static int qp_solve(const orc_ctx* c, const double* q, double alpha, const doubl
                 }
             double t2 = dependent ? INFINITY : -sp / delta;
             double t = t1 < t2 ? t1 : t2;
+#ifdef ORC_TRACE
+            fprintf(stderr, "CPU it=%d p=%d sp=%.17g nq=%d cg=%.17g delta=%.17g t1=%.17g t2=%.17g kdrop=%d dep=%d r0=%.17g u0=%.17g\n", iters, p, sp, nq, cg, delta, t1, t2, kdrop, dependent, nq ? r[0] : 0.0, u[0]);
+#endif
             if (t == INFINITY) { status = LBMPC_ST_QP_INFEASIBLE; goto done; }
             for (int a = 0; a < nq; ++a) u[a] = fma(-t, r[a], u[a]);
             u[nq] += t;

@@ -148,9 +148,10 @@ def test_mrpi_s_alpha(core, P):
     Phi, WV, WA, Wb = P["Phi"], P["W_V"], P["W_A"], P["W_b"]
     D = np.hstack([np.eye(2), -np.eye(2)])
     for eps, s_ref, a_ref in ((0.1, 7, 0.123623), (0.01, 11, 0.0151979)):
-        s, a, Ms, rc = core.mrpi_s_alpha(Phi, WV, WA, Wb, D, eps, mode=_abi.MS_RAKOVIC)
+        s, a, Ms, rc = core.mrpi_s_alpha(Phi, WV, WA, Wb, D, eps, mode=_abi.MS_MAX_LITERAL)
         assert rc == 0 and s == s_ref and abs(a - a_ref) < 1e-6
-        assert (s, a, Ms, rc) == oracle_core.mrpi_s_alpha(Phi, WV, WA, Wb, D, eps, mode=_abi.MS_RAKOVIC)
+        assert (s, a, Ms, rc) == oracle_core.mrpi_s_alpha(Phi, WV, WA, Wb, D, eps, mode=_abi.MS_MAX_LITERAL)
+        assert core.mrpi_s_alpha(Phi, WV, WA, Wb, D, eps, mode=_abi.MS_RAKOVIC) == oracle_core.mrpi_s_alpha(Phi, WV, WA, Wb, D, eps, mode=_abi.MS_RAKOVIC)
         Fc = P["F"] + P["G"] @ P["K"]
         h = core.support_batch(Phi, WV, s, a, Fc.T, transpose=True)
         ref = {0.1: [0.162328, 1.020390], 0.01: [0.149607, 0.933744]}[eps]
