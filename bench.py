@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path on MI355X.
+
+metric (BASELINE.json): "closed-loop MPC steps/sec (batched MC trials, 4x4) + samples/sec set learning".
+  value            = closed-loop UQ-RMPC steps/s, 4x4 system, Case_4-style Monte-Carlo (config C4): every rank runs
+                     --trials trials x --horizon steps per bench step (weak scaling), trials keyed by global id.
+  set_learning     = secondary leg (config C2): halfspace max-reduction + homothety LP over pre-materialised
+                     information sets resident in HBM (2x2, N=20000 per set), samples/s.
+One JSON line on rank 0.  Launch: python bench.py [--gpus N --steps K --warmup W]  (N>1 under torch.distributed.run).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "learning-based-mpc_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X fp64 vector (non-MFMA) peak, BASELINE.md section 2.4
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--trials", type=int, default=131072, help="MC trials per GPU per step (config C4: >= 100k)")
+    ap.add_argument("--horizon", type=int, default=1000, help="K_N closed-loop steps per trial (Case_4: 1000)")
+    ap.add_argument("--card-i0", type=int, default=10, help="card(I_0^w) (Case_4...:21)")
+    ap.add_argument("--system", default="4x4")
+    ap.add_argument("--sl-sets", type=int, default=8192, help="information sets per GPU in the set-learning leg")
+    ap.add_argument("--sl-n", type=int, default=20000, help="samples per information set")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-trials", type=int, default=512)
+    args = ap.parse_args()
+
+    from lbmpc import core, dev, dist as ldist, params
+    rank, world, local = ldist.init_process_group()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    core.init(local)
+    device = torch.device("cuda", local)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---------------------------------------------------------------- primary leg: 4x4 closed-loop MC (C4)
+    P = params.load(args.system)
+    nx, nz = int(P["nx"]), int(P["nx"]) + int(P["N"]) * int(P["nu"])
+    nS, nH = P["S_A"].shape[0], int(P["nc"]) * (int(P["Nu"]) + 1)
+    smp = params.sampler(P)
+    ctx = core.Context(P)
+    x0 = np.zeros(nx)
+    x0[0], x0[1] = -12.0, 5.0                      # Case_4...:27 x_RM_0, zero-padded
+    trial0, _ = args.trials * rank, None
+    bufs = dev.McBuffers(ctx, args.trials, device)
+    mc_kw = dict(steps=args.horizon, card_I0=args.card_i0, seed=4, x0=x0, acc_bound=float(P["acc_bound"][0]),
+                 distance_error=float(P["distance_error"][0]), trial0=trial0)
+
+    def mc_step():
+        dev.mc_run(ctx, smp, bufs, **mc_kw)
+
+    for _ in range(args.warmup):
+        mc_step()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        mc_step()
+        b.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # HIP events on the launch stream
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    # gather of the per-trial statistics (the only exchange of this path)
+    infeas = ldist.gather_trials(bufs.infeasible)
+    iters = ldist.gather_trials(bufs.qp_iters)
+    status = ldist.gather_trials(bufs.status)
+    total_steps = args.trials * world * args.horizon * args.steps
+    value = total_steps / dt
+    iters_local = int(bufs.qp_iters.sum().item())
+    # algorithmic flops of one launch on this GPU (DESIGN.md "Kernel 3"): one pass over the nS rows of S_hat per
+    # MPC step (2 nS nx) + one full pass (2 (nS nx + nH nz)) per active-set iteration
+    flops = args.trials * args.horizon * 2.0 * nS * nx + iters_local * 2.0 * (nS * nx + nH * nz)
+    achieved = flops / (kern_ms * 1e-3) / 1e12
+
+    # ---------------------------------------------------------------- secondary leg: set learning (C2)
+    P2 = params.load(os.path.join(ROOT, "tests", "golden", "params_2x2.npz"))
+    smp2 = params.sampler(P2)
+    B, N = args.sl_sets, args.sl_n
+    samples = torch.empty((B, N, 2), dtype=torch.float64, device=device)
+    m = torch.empty((B, 4), dtype=torch.float64, device=device)
+    dev.sample_information_sets(smp2, P2["W_A"], N, B, seed=2, set0=B * rank, samples=samples, m=m)
+    torch.cuda.synchronize()
+    m_ref = m.clone()
+    alpha = torch.empty(B, dtype=torch.float64, device=device)
+    v = torch.empty((B, 2), dtype=torch.float64, device=device)
+
+    def sl_step():
+        dev.halfspace_max(P2["W_A"], samples, out=m)
+        dev.homothety_lp(P2["W_A"], P2["W_b"], m, alpha, v)
+
+    for _ in range(max(1, args.warmup)):
+        sl_step()
+    barrier()
+    sl_steps = max(10, args.steps)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(sl_steps):
+        sl_step()
+    e1.record()
+    barrier()
+    sl_dt = time.perf_counter() - t0
+    sl_ms = e0.elapsed_time(e1) / sl_steps
+    t2 = torch.tensor([sl_dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+    sl_dt = float(t2.item())
+    assert torch.equal(m, m_ref), "halfspace max differs from the maxima computed at generation time"
+    sl_value = B * N * world * sl_steps / sl_dt
+    sl_bytes = B * N * 2 * 8.0
+    sl_gbs = sl_bytes / (sl_ms * 1e-3) / 1e9
+
+    # ---------------------------------------------------------------- CPU baseline (rank 0, N=1 only)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle_core
+        octx = oracle_core.Context(P)
+        ct = args.cpu_trials
+        t0 = time.perf_counter()
+        o = octx.mc_run(smp, trials=ct, **{**mc_kw, "trial0": 0})
+        cdt = time.perf_counter() - t0
+        # parity spot-check of the benchmarked launch against the oracle on the same trial ids
+        assert np.array_equal(o["infeasible"], bufs.infeasible[:ct].cpu().numpy())
+        assert np.array_equal(o["qp_iters"], bufs.qp_iters[:ct].cpu().numpy())
+        assert np.allclose(o["alpha_final"], bufs.alpha_final[:ct].cpu().numpy(), rtol=1e-9, atol=0)
+        assert np.allclose(o["x_final"], bufs.x_final[:ct].cpu().numpy(), rtol=1e-6, atol=1e-6)
+        cpu = {"value": ct * args.horizon / cdt, "unit": "MPC steps/s", "cores": 1, "kind": "port",
+               "sample": f"{ct} trials x {args.horizon} steps of the same {args.system} workload (trial ids 0..{ct - 1}), "
+                         f"oracle/lbmpc_oracle.c single thread, {cdt:.1f} s; parity of these trials checked against the GPU run",
+               "reference_stored_matlab_steps_per_s": 15.4}
+    if rank == 0:
+        out = {
+            "metric": "closed-loop MPC steps/sec (batched MC trials, 4x4) + samples/sec set learning",
+            "value": value, "unit": "MPC steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"C4: {args.system} UQ-RMPC closed-loop Monte-Carlo, {args.trials} trials/GPU x "
+                                   f"{args.horizon} steps, card(I0)={args.card_i0}, build-generated params_{args.system}.npz",
+                       "trials_per_gpu": args.trials, "horizon": args.horizon, "nS": int(nS), "nH": int(nH), "nz": int(nz),
+                       "parallelism": f"trial-sharded x{world}, no data-path collective"},
+            "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": None, "kernel": "mc_kernel",
+                         "kernel_ms": kern_ms, "algorithmic_flops_per_launch": flops,
+                         "note": "MFMA deliberately unused (north_star); bound is the fp64 vector rate"},
+            "set_learning": {"value": sl_value, "unit": "samples/s", "ms_per_step": sl_ms,
+                             "config": {"workload": f"C2: 2x2 set learning, {B} information sets/GPU x {N} samples resident in HBM"},
+                             "roofline": {"bound": "hbm", "achieved": sl_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": sl_gbs / HBM_PEAK_GBS, "traffic": None, "kernel": "halfspace_max_kernel",
+                                          "algorithmic_bytes_per_launch": sl_bytes}},
+            "mc_stats": {"infeasible_trials": int(infeas.sum().item()), "max_status": int(status.max().item()),
+                         "mean_qp_iters_per_trial": float(iters.double().mean().item())},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
