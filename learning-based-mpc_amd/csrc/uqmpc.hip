@@ -94,53 +94,45 @@ __device__ __forceinline__ double row_dot(const CtxDev* __restrict__ C, const Ld
 }
 
 // Append row `a` (constraint pa, wave-uniform) to the Cholesky factor of M = C_A Ginv C_A'.
-// Uniform sequential work executed redundantly by all lanes; lane 0 stores the row.
+// Lane b holds M[a][b] = c_pa . Wm[b]; the row solve L y = M[a][0..a) is a column sweep (ascending k,
+// the oracle's order), y_k broadcast by readlane; lane a accumulates the diagonal.
 __device__ __forceinline__ void chol_append(const CtxDev* __restrict__ C, const LdsView& L, const WsView& ws,
                                             int a, int pa, int lane) {
     const int nz = C->nz;
-    double Lrow[NZMAX];
-#pragma unroll
-    for (int b = 0; b < NZMAX; ++b) {
-        if (b <= a) {
-            double acc = row_dot(C, L, pa, ws.Wm + b * nz);
-#pragma unroll
-            for (int k = 0; k < NZMAX; ++k)
-                if (k < b) acc = fma(-Lrow[k], (b < a) ? ws.L[b * nz + k] : Lrow[k], acc);
-            if (b < a) Lrow[b] = acc / ws.L[b * nz + b];
-            else Lrow[b] = sqrt(acc > 0.0 ? acc : 0.0);
-        }
+    double acc = 0.0;
+    if (lane <= a) acc = row_dot(C, L, pa, ws.Wm + lane * nz);
+    for (int k = 0; k < a; ++k) {
+        const double yk = readlane_f64(acc, k) / ws.L[k * nz + k];
+        if (lane == k) acc = yk;
+        else if (lane > k && lane < a) acc = fma(-yk, ws.L[lane * nz + k], acc);
+        else if (lane == a) acc = fma(-yk, yk, acc);
     }
-    wave_sync();
-    if (lane == 0) {
-#pragma unroll
-        for (int b = 0; b < NZMAX; ++b)
-            if (b <= a) ws.L[a * nz + b] = Lrow[b];
-    }
+    if (lane == a) acc = sqrt(acc > 0.0 ? acc : 0.0);
+    if (lane <= a) ws.L[a * nz + lane] = acc;
     wave_sync();
 }
 
 // Wave-cooperative Goldfarb-Idnani dual active-set solve of
 //   min z'Pz  s.t.  alpha S_b + S_A (q + s0) >= 0,  (1-h) - H z >= 0      (UQRobustMPC.m:149-155)
-// from z = 0.  alpha, q[] wave-uniform; ws.omh[] holds 1-h_k.  (p0, sp0) = first pivot found by the
-// caller's pass at z = 0.  Result: ws.z, ws.act[0..nact).  Same arithmetic as the oracle's qp_solve.
+// from z = 0.  alpha, q[] wave-uniform; ws.omh[] holds 1-h_k.  Result: ws.z, ws.act[0..nact).
+// Lane a carries active constraint a (row id, multiplier u_a, r_a); lane k < nz carries z_k, g_k.
+// Same arithmetic, operation order and tie rules as the oracle's qp_solve.
 template <int NX>
-__device__ int coop_qp_solve(const CtxDev* __restrict__ C, const LdsView& L, const WsView& ws, double alpha,
-                             const double* q, int p0, double sp0, int& nact_out, int& iters_out) {
+__device__ __forceinline__ int coop_qp_solve(const CtxDev* __restrict__ C, const LdsView& L, const WsView& ws,
+                                             double alpha, const double* q, int& nact_out, int& iters_out) {
     const int lane = lane_id();
     const int nz = C->nz, nS = C->nS, nH = C->nH, nc = C->nc, RL = C->RL, nzp = C->nzp;
     int nq = 0, iters = 0, status = 0;
     uint64_t actS = 0, actH = 0;  // bit i: my i-th S row (lane + 64 i) / H row is active
-    double u[NZMAX + 1];
-#pragma unroll
-    for (int a = 0; a <= NZMAX; ++a) u[a] = 0.0;
+    double my_u = 0.0, my_z = 0.0;
+    int my_act = -1;
     if (lane < NZMAX) ws.z[lane] = 0.0;
     wave_sync();
-    int p = p0;
-    double sp = sp0;
-    bool have_pivot = true;
     for (;;) {
-        if (!have_pivot) {
-            // Step 1: most violated row at the current z
+        // Step 1: most violated row at the current z
+        int p;
+        double sp;
+        {
             double zr[NZMAX], e[NX];
 #pragma unroll
             for (int k = 0; k < NZMAX; ++k) zr[k] = (k < nz) ? ws.z[k] : 0.0;
@@ -173,112 +165,91 @@ __device__ int coop_qp_solve(const CtxDev* __restrict__ C, const LdsView& L, con
             if (bj == 0x7fffffff) break;  // optimal
             p = bj; sp = best;
         }
-        have_pivot = false;
         // g = Ginv c_p ; cg = c_p . g
+        double my_g = 0.0;
         if (lane < nz) {
             double acc = 0.0;
             if (p < nS) { for (int k = 0; k < NX; ++k) acc = fma(L.Ginv[lane * nz + k], -L.Srow[p * RL + 1 + k], acc); }
             else { const double* h = L.Hm + (p - nS) * nzp; for (int k = 0; k < nz; ++k) acc = fma(L.Ginv[lane * nz + k], h[k], acc); }
-            ws.g[lane] = acc;
+            ws.g[lane] = my_g = acc;
         }
         wave_sync();
         const double cg = row_dot(C, L, p, ws.g);
-#pragma unroll
-        for (int a = 0; a <= NZMAX; ++a) if (a == nq) u[a] = 0.0;
+        if (lane == nq) my_u = 0.0;
         // Step 2
-        bool added = false;
-        while (!added) {
+        for (;;) {
             if (++iters > QP_MAX_ITERS) { status = LBMPC_ST_ITER_CAP; goto done; }
-            double r[NZMAX];
-#pragma unroll
-            for (int a = 0; a < NZMAX; ++a) r[a] = 0.0;
-            double delta = cg;
+            double my_r = 0.0, my_rhs = 0.0, delta = cg;
             if (nq > 0) {
-                if (lane < nq) ws.rhs[lane] = row_dot(C, L, ws.act[lane], ws.g);
-                wave_sync();
-                // forward / backward substitution with the maintained factor (uniform, redundant)
-#pragma unroll
-                for (int a = 0; a < NZMAX; ++a)
-                    if (a < nq) {
-                        double acc = ws.rhs[a];
-#pragma unroll
-                        for (int k = 0; k < NZMAX; ++k) if (k < a) acc = fma(-ws.L[a * nz + k], r[k], acc);
-                        r[a] = acc / ws.L[a * nz + a];
-                    }
-#pragma unroll
-                for (int a = NZMAX - 1; a >= 0; --a)
-                    if (a < nq) {
-                        double acc = r[a];
-#pragma unroll
-                        for (int k = 0; k < NZMAX; ++k) if (k > a && k < nq) acc = fma(-ws.L[k * nz + a], r[k], acc);
-                        r[a] = acc / ws.L[a * nz + a];
-                    }
-#pragma unroll
-                for (int a = 0; a < NZMAX; ++a) if (a < nq) delta = fma(-ws.rhs[a], r[a], delta);
-            }
-            // primal direction, component `lane`
-            double zd = 0.0;
-            if (lane < nz) {
-                double acc = ws.g[lane];
-#pragma unroll
-                for (int a = 0; a < NZMAX; ++a) if (a < nq) acc = fma(-ws.Wm[a * nz + lane], r[a], acc);
-                zd = -acc;
-            }
-            const bool dependent = (nq >= nz) || !(delta > QP_TOL_DEP * cg);
-            double t1 = LB_INF, rmax = 0.0;
-            int kdrop = -1;
-#pragma unroll
-            for (int a = 0; a < NZMAX; ++a) if (a < nq && fabs(r[a]) > rmax) rmax = fabs(r[a]);
-#pragma unroll
-            for (int a = 0; a < NZMAX; ++a)
-                if (a < nq && r[a] > QP_TOL_R * rmax) {
-                    double t = u[a] / r[a];
-                    if (t < t1) { t1 = t; kdrop = a; }
+                if (lane < nq) my_rhs = row_dot(C, L, my_act, ws.g);
+                double acc = my_rhs;
+                for (int k = 0; k < nq; ++k) {  // L y = rhs
+                    const double yk = readlane_f64(acc, k) / ws.L[k * nz + k];
+                    if (lane == k) acc = yk;
+                    else if (lane > k && lane < nq) acc = fma(-ws.L[lane * nz + k], yk, acc);
                 }
+                for (int k = nq - 1; k >= 0; --k) {  // L' r = y
+                    const double rk = readlane_f64(acc, k) / ws.L[k * nz + k];
+                    if (lane == k) acc = rk;
+                    else if (lane < k) acc = fma(-ws.L[k * nz + lane], rk, acc);
+                }
+                my_r = (lane < nq) ? acc : 0.0;
+                for (int a = 0; a < nq; ++a) delta = fma(-readlane_f64(my_rhs, a), readlane_f64(my_r, a), delta);
+            }
+            // primal direction, component `lane`: zd = -(g - Wm' r)
+            double zacc = my_g;
+            for (int a = 0; a < nq; ++a) {
+                const double ra = readlane_f64(my_r, a);
+                if (lane < nz) zacc = fma(-ws.Wm[a * nz + lane], ra, zacc);
+            }
+            const double zd = -zacc;
+            const bool dependent = (nq >= nz) || !(delta > QP_TOL_DEP * cg);
+            const double rmax = wave_max((lane < nq) ? fabs(my_r) : 0.0);
+            double t1 = LB_INF;
+            int kdrop = 0x7fffffff;
+            if (lane < nq && my_r > QP_TOL_R * rmax) { t1 = my_u / my_r; kdrop = lane; }
+            wave_argmin(t1, kdrop);
             const double t2 = dependent ? LB_INF : -sp / delta;
             const double t = t1 < t2 ? t1 : t2;
 #ifdef LBMPC_TRACE
-            if (lane == 0) printf("GPU it=%d p=%d sp=%.17g nq=%d cg=%.17g delta=%.17g t1=%.17g t2=%.17g kdrop=%d dep=%d r0=%.17g u0=%.17g\n", iters, p, sp, nq, cg, delta, t1, t2, kdrop, (int)dependent, r[0], u[0]);
+            if (lane == 0) printf("GPU it=%d p=%d sp=%.17g nq=%d cg=%.17g delta=%.17g t1=%.17g t2=%.17g kdrop=%d dep=%d r0=%.17g u0=%.17g\n", iters, p, sp, nq, cg, delta, t1, t2, kdrop == 0x7fffffff ? -1 : kdrop, (int)dependent, my_r, my_u);
 #endif
             if (t == LB_INF) { status = LBMPC_ST_QP_INFEASIBLE; goto done; }
-#pragma unroll
-            for (int a = 0; a < NZMAX; ++a) if (a < nq) u[a] = fma(-t, r[a], u[a]);
-#pragma unroll
-            for (int a = 0; a <= NZMAX; ++a) if (a == nq) u[a] += t;
+            if (lane < nq) my_u = fma(-t, my_r, my_u);
+            if (lane == nq) my_u += t;
             if (!dependent) {
-                if (lane < nz) ws.z[lane] = fma(t, zd, ws.z[lane]);
+                if (lane < nz) { my_z = fma(t, zd, my_z); ws.z[lane] = my_z; }
                 sp = fma(t, delta, sp);
             }
             wave_sync();
             if (!dependent && t2 <= t1) {
                 // full step: constraint p joins the active set
-                if (lane < nz) ws.Wm[nq * nz + lane] = ws.g[lane];
-                if (lane == 0) ws.act[nq] = p;
+                if (lane < nz) ws.Wm[nq * nz + lane] = my_g;
+                if (lane == nq) my_act = p;
                 wave_sync();
                 chol_append(C, L, ws, nq, p, lane);
                 if (p < nS) { if ((p & 63) == lane) actS |= 1ull << (p >> 6); }
                 else { int h = p - nS; if ((h & 63) == lane) actH |= 1ull << (h >> 6); }
                 nq++;
-                added = true;
-            } else {
-                // drop active constraint kdrop, stay in step 2
-                const int pd = ws.act[kdrop];
-                if (pd < nS) { if ((pd & 63) == lane) actS &= ~(1ull << (pd >> 6)); }
-                else { int h = pd - nS; if ((h & 63) == lane) actH &= ~(1ull << (h >> 6)); }
-                int moved = (lane >= kdrop && lane < nq - 1) ? ws.act[lane + 1] : 0;
-                wave_sync();
-                if (lane >= kdrop && lane < nq - 1) ws.act[lane] = moved;
-                if (lane < nz)
-                    for (int a = kdrop; a < nq - 1; ++a) ws.Wm[a * nz + lane] = ws.Wm[(a + 1) * nz + lane];
-#pragma unroll
-                for (int a = 0; a < NZMAX; ++a) if (a >= kdrop && a < nq) u[a] = u[a + 1];
-                nq--;
-                wave_sync();
-                for (int a = kdrop; a < nq; ++a) chol_append(C, L, ws, a, ws.act[a], lane);
+                break;
             }
+            // drop active constraint kdrop, stay in step 2
+            const int pd = __builtin_amdgcn_readlane(my_act, kdrop);
+            if (pd < nS) { if ((pd & 63) == lane) actS &= ~(1ull << (pd >> 6)); }
+            else { int h = pd - nS; if ((h & 63) == lane) actH &= ~(1ull << (h >> 6)); }
+            const int nxt_act = __shfl_down(my_act, 1, LB_WAVE);
+            const double nxt_u = __shfl_down(my_u, 1, LB_WAVE);
+            if (lane >= kdrop && lane < nq) { my_act = nxt_act; my_u = nxt_u; }
+            if (lane < nz)
+                for (int a = kdrop; a < nq - 1; ++a) ws.Wm[a * nz + lane] = ws.Wm[(a + 1) * nz + lane];
+            nq--;
+            wave_sync();
+            for (int a = kdrop; a < nq; ++a) chol_append(C, L, ws, a, __builtin_amdgcn_readlane(my_act, a), lane);
         }
     }
 done:
+    if (lane < nq) ws.act[lane] = my_act;
+    wave_sync();
     nact_out = nq;
     iters_out = iters;
     return status;
@@ -352,32 +323,34 @@ __device__ __forceinline__ double hk_value(const CtxDev* __restrict__ C, double 
     return alpha * C->hs[r] + (1.0 - alpha) * g;
 }
 
-// First pass at z = 0 for the T trials of this lane: slack_j = alpha S_b[j] + S_A[j,:].q for the S rows
-// (LDS broadcast of the row), and 1-h_k[r] for the first block of H rows.
+// First pass at z = 0 for the T trials of this lane: min_j slack_j with slack_j = alpha S_b[j] + S_A[j,:].q over
+// the S rows (each row one LDS broadcast, shared by the 64*T trials of the wave); the H rows contribute
+// exactly 1-h_k[r] at z = 0.  Only "is any row violated" is needed here: the pivot itself is found by
+// the cooperative solver, which recomputes the same values.
 template <int NX, int T>
 __device__ __forceinline__ void first_pass(const CtxDev* __restrict__ C, const LdsView& L, const double* alpha,
-                                           const double (*q)[NX], const double* min_omh, const int* arg_omh,
-                                           double* best, int* bidx) {
+                                           const double (*q)[NX], const double* min_omh, bool* need) {
+    double mn[T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) { best[t] = -QP_TOL_VIOL; bidx[t] = -1; }
-    const int nS = C->nS, RL = C->RL;
-    const double* row = L.Srow;
-    for (int j = 0; j < nS; ++j, row += RL) {
-        const double sb = row[0];
-        double a[NX];
+    for (int t = 0; t < T; ++t) mn[t] = min_omh[t];
+    const int nS = C->nS;
+    constexpr int RLc = (NX + 2) & ~1;  // == C->RL
+    const double2* row = reinterpret_cast<const double2*>(L.Srow);
+#pragma unroll 4
+    for (int j = 0; j < nS; ++j, row += RLc / 2) {
+        double c[RLc];
 #pragma unroll
-        for (int k = 0; k < NX; ++k) a[k] = row[1 + k];
+        for (int i = 0; i < RLc / 2; ++i) { double2 t2 = row[i]; c[2 * i] = t2.x; c[2 * i + 1] = t2.y; }
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            double acc = alpha[t] * sb;
+            double acc = alpha[t] * c[0];
 #pragma unroll
-            for (int k = 0; k < NX; ++k) acc = fma(a[k], q[t][k], acc);
-            if (acc < best[t]) { best[t] = acc; bidx[t] = j; }
+            for (int k = 0; k < NX; ++k) acc = fma(c[1 + k], q[t][k], acc);
+            mn[t] = acc < mn[t] ? acc : mn[t];
         }
     }
 #pragma unroll
-    for (int t = 0; t < T; ++t)
-        if (min_omh[t] < best[t]) { best[t] = min_omh[t]; bidx[t] = nS + arg_omh[t]; }
+    for (int t = 0; t < T; ++t) need[t] = mn[t] < -QP_TOL_VIOL;
 }
 
 __device__ __forceinline__ void stage_constants(const CtxDev* __restrict__ C, double* lds) {
@@ -392,8 +365,8 @@ __device__ __forceinline__ void stage_constants(const CtxDev* __restrict__ C, do
 // Owner lane receives: z_head[0..NX) = s0, z_u[0..nu) = c(1:nu), status, iters.
 template <int NX>
 __device__ __forceinline__ void solve_flagged(const CtxDev* __restrict__ C, const LdsView& L, const WsView& ws,
-                                              bool need, double alpha, const double* v, const double* q, int p0,
-                                              double sp0, double* s0, double* c0, int& status, int& iters,
+                                              bool need, double alpha, const double* v, const double* q,
+                                              double* s0, double* c0, int& status, int& iters,
                                               int* nact_out, int* act_out /* NZMAX, sorted, or null */,
                                               double* c_full /* nz-NX or null */) {
     const int lane = lane_id();
@@ -405,13 +378,11 @@ __device__ __forceinline__ void solve_flagged(const CtxDev* __restrict__ C, cons
         const double a_u = readlane_f64(alpha, src);
 #pragma unroll
         for (int k = 0; k < NX; ++k) qa[k] = readlane_f64(q[k], src);
-        const int p_u = __builtin_amdgcn_readlane(p0, src);
-        const double sp_u = readlane_f64(sp0, src);
         if (lane == src)
             for (int r = 0; r < C->nc; ++r) ws.omh[r] = 1.0 - hk_value<NX>(C, alpha, v, r);
         wave_sync();
         int nact = 0, it = 0;
-        const int st = coop_qp_solve<NX>(C, L, ws, a_u, qa, p_u, sp_u, nact, it);
+        const int st = coop_qp_solve<NX>(C, L, ws, a_u, qa, nact, it);
         wave_sync();
         if (lane == src) {
 #pragma unroll
@@ -456,15 +427,16 @@ __global__ __launch_bounds__(256) void uqmpc_step_kernel(const CtxDev* __restric
         const int64_t b = base + lane;
         const bool valid = b < batch;
         const int64_t bb = valid ? b : batch - 1;
-        double x[NX], v[NX], w[NX], q[1][NX], bh[2 * NX], alpha[1], momh[1], best[1];
-        int aomh[1], bidx[1], status = 0, iters = 0, nact = 0;
+        double x[NX], v[NX], w[NX], q[1][NX], bh[2 * NX], alpha[1], momh[1];
+        int aomh[1], status = 0, iters = 0, nact = 0;
+        bool need[1];
 #pragma unroll
         for (int k = 0; k < NX; ++k) { x[k] = io.x[bb * NX + k]; v[k] = io.v_prev[bb * NX + k]; w[k] = (uq && io.w_new) ? io.w_new[bb * NX + k] : 0.0; }
         alpha[0] = io.alpha_prev[bb];
         if (uq) status = uq_update<NX>(C, alpha[0], v, w, bh);
         else w_hat_b<NX>(C, alpha[0], v, bh);
         tighten<NX>(C, alpha[0], v, x, q[0], momh[0], aomh[0]);
-        first_pass<NX, 1>(C, L, alpha, q, momh, aomh, best, bidx);
+        first_pass<NX, 1>(C, L, alpha, q, momh, need);
         double s0[NX], c0[LBMPC_MAX_NU];
 #pragma unroll
         for (int k = 0; k < NX; ++k) s0[k] = 0.0;
@@ -474,7 +446,7 @@ __global__ __launch_bounds__(256) void uqmpc_step_kernel(const CtxDev* __restric
         double* cdst = (valid && io.c) ? io.c + b * ncv : nullptr;
         if (cdst) for (int k = 0; k < ncv; ++k) cdst[k] = 0.0;
         if (valid && io.active_set) for (int a = 0; a < NZMAX; ++a) io.active_set[b * NZMAX + a] = -1;
-        solve_flagged<NX>(C, L, ws, valid && bidx[0] >= 0, alpha[0], v, q[0], bidx[0], best[0], s0, c0, status, iters,
+        solve_flagged<NX>(C, L, ws, valid && need[0], alpha[0], v, q[0], s0, c0, status, iters,
                           &nact, (valid && io.active_set) ? io.active_set + b * NZMAX : nullptr, cdst);
         (void)act_sorted;
         if (!valid) continue;
@@ -582,8 +554,9 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
             }
         }
         for (int k = 0; k < K; ++k) {
-            double q[T][NX], xi_lv[T][NX], Bul[T][NX], momh[T], best[T];
-            int aomh[T], bidx[T];
+            double q[T][NX], xi_lv[T][NX], Bul[T][NX], momh[T];
+            int aomh[T];
+            bool need[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 // LVModeling first (Case_3...:58; ModelingCar.m:42-43)
@@ -595,7 +568,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
                 status[t] = st > status[t] ? st : status[t];
                 tighten<NX>(C, alpha[t], v[t], x[t], q[t], momh[t], aomh[t]);
             }
-            first_pass<NX, T>(C, L, alpha, q, momh, aomh, best, bidx);
+            first_pass<NX, T>(C, L, alpha, q, momh, need);
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 double s0[NX], c0[LBMPC_MAX_NU], u[LBMPC_MAX_NU];
@@ -603,7 +576,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
                 for (int i = 0; i < NX; ++i) s0[i] = 0.0;
 #pragma unroll
                 for (int j = 0; j < LBMPC_MAX_NU; ++j) c0[j] = 0.0;
-                solve_flagged<NX>(C, L, ws, valid[t] && bidx[t] >= 0, alpha[t], v[t], q[t], bidx[t], best[t], s0, c0,
+                solve_flagged<NX>(C, L, ws, valid[t] && need[t], alpha[t], v[t], q[t], s0, c0,
                                   status[t], iters[t], nullptr, nullptr, nullptr);
                 // u = K x + c(1:nu); EVModeling (ModelingCar.m:36-37); relative dynamics
                 double xi_ev[NX], Ax[NX], Bu[NX], xn[NX];
@@ -719,7 +692,7 @@ extern "C" int lbmpc_uqmpc_create(const lbmpc_params* p, lbmpc_ctx** out) {
     std::memset(&h, 0, sizeof(h));
     if (int rc = pack_box(p->W_A, p->W_b, p->nW, nx, &h.box)) { delete c; return rc; }
     h.nx = nx; h.nu = nu; h.N = N; h.nc = nc; h.Nu = p->Nu; h.nS = nS; h.nW = p->nW; h.nz = nz; h.nH = nH;
-    h.RL = (nx + 1) | 1;
+    h.RL = (nx + 2) & ~1;  // [S_b, S_A row, pad] with an even pitch: rows are read as double2 broadcasts
     h.nzp = nz | 1;
     for (int i = 0; i < nx; ++i) for (int j = 0; j < nx; ++j) h.A[i * nx + j] = CMX(p->A, nx, i, j);
     for (int i = 0; i < nx; ++i) for (int j = 0; j < nu; ++j) h.B[i * nu + j] = CMX(p->B, nx, i, j);
@@ -874,7 +847,9 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
     a.traj_trials = cfg->traj_trials; a.sampler_max_attempts = cfg->sampler_max_attempts;
     a.out = *out;
     // T = 2 trials per lane once there are enough trials to fill the chip at that width
-    const bool wide = cfg->trials >= (int64_t)256 * 4 * 128;
+    // T = 2 trials per lane once 2-per-lane still fills every CU with a full block
+    const char* env_t = getenv("LBMPC_MC_T");
+    const bool wide = env_t ? (atoi(env_t) == 2) : (cfg->trials >= (int64_t)256 * 8 * 128);
     const int waves = pick_waves(c, 8);
     if (!waves) { set_error("constants (%zu B) do not fit in LDS", c->lds_const_bytes); return LBMPC_ERR_DIM; }
     const size_t lds = c->lds_const_bytes + (size_t)waves * ws_doubles(c->h.nz) * 8;

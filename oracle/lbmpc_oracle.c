@@ -628,9 +628,9 @@ static int qp_solve(const orc_ctx* c, const double* q, double alpha, const doubl
                     for (int k = 0; k < a; ++k) acc = fma(-L[a][k], r[k], acc);
                     r[a] = acc / L[a][a];
                 }
-                for (int a = nq - 1; a >= 0; --a) { /* backward */
+                for (int a = nq - 1; a >= 0; --a) { /* backward (terms applied in descending k: a column sweep) */
                     double acc = r[a];
-                    for (int k = a + 1; k < nq; ++k) acc = fma(-L[k][a], r[k], acc);
+                    for (int k = nq - 1; k > a; --k) acc = fma(-L[k][a], r[k], acc);
                     r[a] = acc / L[a][a];
                 }
                 for (int a = 0; a < nq; ++a) delta = fma(-rhs[a], r[a], delta);

@@ -296,13 +296,17 @@ def test_mc_sharding_invariance(core, P, smp):
 
 
 def test_mc_wide_path_matches_narrow(core, P, smp):
-    """>= 131072 trials switches to 2 trials per lane; its first trials must equal a small (1 per lane) run"""
+    """2 trials per lane (chosen automatically from 262144 trials; forced here) == 1 trial per lane, bitwise"""
+    import os
     ctx = core.Context(P)
-    kw = dict(steps=6, card_I0=10, seed=4, x0=[-12.0, 5.0], acc_bound=2.0, distance_error=15.0)
-    big = ctx.mc_run(smp, trials=131072 + 77, **kw)
-    small = ctx.mc_run(smp, trials=500, **kw)
-    tail = ctx.mc_run(smp, trials=77, trial0=131072, **kw)
+    kw = dict(trials=1000, steps=8, card_I0=10, seed=4, x0=[-12.0, 5.0], acc_bound=2.0, distance_error=15.0)
+    try:
+        os.environ["LBMPC_MC_T"] = "2"
+        wide = ctx.mc_run(smp, **kw)
+        os.environ["LBMPC_MC_T"] = "1"
+        narrow = ctx.mc_run(smp, **kw)
+    finally:
+        os.environ.pop("LBMPC_MC_T", None)
     for k in ("infeasible", "status", "qp_iters", "alpha_final", "v_final", "x_final"):
-        np.testing.assert_array_equal(big[k][:500], small[k], err_msg=k)
-        np.testing.assert_array_equal(big[k][131072:], tail[k], err_msg=k)
+        np.testing.assert_array_equal(wide[k], narrow[k], err_msg=k)
     ctx.close()
