@@ -137,6 +137,15 @@ int lbmpc_sample_information_sets_dev(const lbmpc_sampler* smp, const double* WA
                                       double* samples_out_dev, double* m_out_dev, int* status_out_dev,
                                       void* stream);
 
+/* n points uniform on {x : XA x <= Xb} (XA: nr x nx) by rejection from the box [lo, hi]: point i is draw
+ * (seed, stream, index0 + i, purpose) of the library's Philox stream, `purpose` in 0..15 selecting an independent
+ * sub-stream.  out: nx x n.  status_out (n ints, may be NULL): LBMPC_ST_SAMPLER_CAP where max_attempts was hit.
+ * Replaces polytope_sample_EV/_LV of Functions_general/ModelingCar.m:47-91 and
+ * InitialSetComputation.m:101-130 when the caller drives the plant itself (Case_3...:58,75). */
+int lbmpc_sample_polytope(const double* XA, const double* Xb, int nr, int nx, const double* lo, const double* hi,
+                          int64_t n, uint64_t seed, uint64_t stream, uint32_t index0, int purpose, int max_attempts,
+                          double* out, int* status_out);
+
 /* The homothety LP  max beta  s.t. 0<=beta<=1, WA y <= beta Wb, beta Wb - WA y <= Wb - m
  * (alpha = 1-beta, v = y/beta), one problem per column of m (nW x batch).
  * Replaces Functions_general/InitialSetComputation.m:69-83,:85-99 (LP, LP_opt) and

@@ -351,6 +351,53 @@ extern "C" int lbmpc_sample_information_sets(const lbmpc_sampler* smp, const dou
     return 0;
 }
 
+// ---- stand-alone polytope sampler (ModelingCar.m:47-91) -------------------------------------------
+namespace lbmpc {
+struct PolyDev {
+    int nr;
+    double A[LBMPC_MAX_NXI * LBMPC_MAX_NX], b[LBMPC_MAX_NXI], lo[LBMPC_MAX_NX], hi[LBMPC_MAX_NX];
+};
+template <int NX>
+__global__ __launch_bounds__(256) void sample_polytope_kernel(PolyDev P, int64_t n, uint64_t seed, uint64_t stream,
+                                                              uint32_t index0, uint32_t purpose, int max_attempts,
+                                                              double* __restrict__ out, int* __restrict__ status) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double x[NX];
+    const bool cap = sample_polytope<NX>(P.A, P.b, P.nr, P.lo, P.hi, seed, stream, index0 + (uint32_t)i, purpose, max_attempts, x);
+#pragma unroll
+    for (int k = 0; k < NX; ++k) out[i * NX + k] = x[k];
+    if (status) status[i] = cap ? LBMPC_ST_SAMPLER_CAP : 0;
+}
+}  // namespace lbmpc
+
+extern "C" int lbmpc_sample_polytope(const double* XA, const double* Xb, int nr, int nx, const double* lo,
+                                     const double* hi, int64_t n, uint64_t seed, uint64_t stream, uint32_t index0,
+                                     int purpose, int max_attempts, double* out, int* status_out) {
+    if (int rc = check_device()) return rc;
+    if (!XA || !Xb || !lo || !hi || !out || n < 0 || nr < 1 || nx < 1 || purpose < 0 || purpose > 15 || max_attempts < 1) { set_error("lbmpc_sample_polytope: bad argument"); return LBMPC_ERR_ARG; }
+    if (nx > LBMPC_MAX_NX || nr > LBMPC_MAX_NXI) { set_error("lbmpc_sample_polytope: nx<=%d rows<=%d", LBMPC_MAX_NX, LBMPC_MAX_NXI); return LBMPC_ERR_DIM; }
+    if (n == 0) return 0;
+    PolyDev P;
+    P.nr = nr;
+    for (int r = 0; r < nr; ++r) { for (int k = 0; k < nx; ++k) P.A[r * nx + k] = XA[r + (size_t)nr * k]; P.b[r] = Xb[r]; }
+    for (int k = 0; k < nx; ++k) { P.lo[k] = lo[k]; P.hi[k] = hi[k]; }
+    DevBuf dout, dst;
+    LB_HIP(dout.alloc((size_t)n * nx * 8));
+    LB_HIP(dst.alloc((size_t)n * 4));
+    dim3 grid((unsigned)((n + 255) / 256));
+    switch (nx) {
+        case 1: hipLaunchKernelGGL(sample_polytope_kernel<1>, grid, dim3(256), 0, nullptr, P, n, seed, stream, index0, (uint32_t)purpose, max_attempts, dout.as<double>(), dst.as<int>()); break;
+        case 2: hipLaunchKernelGGL(sample_polytope_kernel<2>, grid, dim3(256), 0, nullptr, P, n, seed, stream, index0, (uint32_t)purpose, max_attempts, dout.as<double>(), dst.as<int>()); break;
+        case 3: hipLaunchKernelGGL(sample_polytope_kernel<3>, grid, dim3(256), 0, nullptr, P, n, seed, stream, index0, (uint32_t)purpose, max_attempts, dout.as<double>(), dst.as<int>()); break;
+        default: hipLaunchKernelGGL(sample_polytope_kernel<4>, grid, dim3(256), 0, nullptr, P, n, seed, stream, index0, (uint32_t)purpose, max_attempts, dout.as<double>(), dst.as<int>()); break;
+    }
+    LB_HIP(hipGetLastError());
+    LB_HIP(hipMemcpy(out, dout.p, (size_t)n * nx * 8, hipMemcpyDeviceToHost));
+    if (status_out) LB_HIP(hipMemcpy(status_out, dst.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 // ---- homothety LP -------------------------------------------------------------------------------
 namespace lbmpc {
 

@@ -1,0 +1,243 @@
+"""Host-side mirror of the reference's MATLAB entry points for the hot path (same names, argument meaning and
+outputs), every numeric step done by liblbmpc_hip.so through the C ABI:
+
+    Fs = MRPISet(Ak, W, epsilon)                                   Functions_general/MRPISet.m:5
+    IniSet = InitialSetComputation(opts); IniSet.solve(); IniSet.solve_opt(samples)   InitialSetComputation.m:28,48,61
+    mpc = UQRobustMPC(opts); mpc.solve(x_k, alpha_before, v_before, w_new)            UQRobustMPC.m:39,68
+    rmpc = NominalRobustMPC(opts); rmpc.solve(x_k)                                    NominalRobustMPC.m:28,47
+    Car = ModelingCar(opts); Car.EVModeling(x, u); Car.LVModeling(x)                  ModelingCar.m:21,34,40
+    monte_carlo(...)                                               loops of Cases_general/Case_{3,4,5}
+
+`opts` are dicts with the reference's field names; MPT3 Polyhedra are `Polyhedron(A=, b=, V=)` objects here.
+The reference is MATLAB (no toolchain in the build image): this Python layer is the stand-in for the thin `.m`
+wrappers + MEX gateway of learning-based-mpc_amd/matlab/ (INTEGRATION.md).
+"""
+import itertools
+
+import numpy as np
+
+from . import _abi, core
+from ._abi import dptr, fcol, iptr
+
+
+class Polyhedron:
+    """The subset of MPT3's Polyhedron the hot path touches: H-rep (.A, .b), V-rep (.V), scalar * P, P + vector."""
+
+    def __init__(self, V=None, A=None, b=None):
+        self.A = None if A is None else np.asarray(A, dtype=np.float64)
+        self.b = None if b is None else np.asarray(b, dtype=np.float64).ravel()
+        self.V = None if V is None else np.asarray(V, dtype=np.float64)
+        if self.A is None and self.V is None:
+            raise ValueError("Polyhedron needs V or (A, b)")
+
+    @property
+    def Dim(self):
+        return (self.A if self.A is not None else self.V).shape[1]
+
+    def __rmul__(self, s):
+        s = float(s)
+        return Polyhedron(V=None if self.V is None else s * self.V, A=self.A, b=None if self.b is None else s * self.b)
+
+    def __add__(self, t):
+        t = np.asarray(t, dtype=np.float64).ravel()
+        return Polyhedron(V=None if self.V is None else self.V + t, A=self.A,
+                          b=None if self.b is None else self.b + self.A @ t)
+
+    __radd__ = __add__
+
+    def box_vertices(self):
+        """vertices of an axis-aligned box given in H-rep (what W is in every reference configuration)"""
+        nx = self.A.shape[1]
+        lo, hi = np.zeros(nx), np.zeros(nx)
+        for a, b in zip(self.A, self.b):
+            k = int(np.abs(a).argmax())
+            if a[k] > 0:
+                hi[k] = b / a[k]
+            else:
+                lo[k] = b / a[k]
+        return np.array(list(itertools.product(*zip(lo, hi))))
+
+    def vertices(self):
+        return self.V if self.V is not None else self.box_vertices()
+
+    def volume(self):
+        """box volume (Case_2...:25 / Case_4...:63 call W_hat.volume() on homothets of the box W)"""
+        V = self.vertices()
+        return float(np.prod(V.max(0) - V.min(0)))
+
+
+def reference_directions(nx, rng):
+    """direction set of MRPISet.m:14-25: [+-I; +-1/sqrt(nx) (nx>2); 10 random unit directions]"""
+    E = np.eye(nx)
+    D = [E, -E]
+    if nx > 2:
+        D += [np.ones((1, nx)) / np.sqrt(nx), -np.ones((1, nx)) / np.sqrt(nx)]
+    extra = rng.normal(size=(10, nx))
+    D.append(extra / np.linalg.norm(extra, axis=1, keepdims=True))
+    return np.vstack(D)
+
+
+def MRPISet(Ak, W, epsilon, template_directions=None, mode=_abi.MS_MAX_LITERAL, seed=0, return_info=False):
+    """epsilon-outer mRPI set of x+ = Ak x + w, w in W.  (s, alpha) by the loop of MRPISet.m:27-63 on the device;
+    the set itself is returned as the H-rep template polytope {x : d_j' x <= h_S(d_j)} of the exact Minkowski-sum
+    support (1-alpha)^-1 sum_{t<s} h_W((Ak^t)' d), evaluated by the batched support kernel, instead of the
+    reference's hull of 200*nx SOCP-projected random samples (MRPISet.m:66-136; SURVEY.md hard part 4)."""
+    Ak = np.asarray(Ak, dtype=np.float64)
+    nx = Ak.shape[0]
+    rng = np.random.default_rng(seed)
+    WV = W.vertices()
+    s, alpha, Ms, rc = core.mrpi_s_alpha(Ak, WV, W.A, W.b, reference_directions(nx, rng).T, epsilon, mode=mode)
+    if template_directions is None:
+        n = {1: 2, 2: 128, 3: 795, 4: 1644}.get(nx, 1644)
+        D = rng.normal(size=(n, nx))
+        template_directions = np.vstack([np.eye(nx), -np.eye(nx), D / np.linalg.norm(D, axis=1, keepdims=True)])
+    D = np.asarray(template_directions, dtype=np.float64)
+    h = core.support_batch(Ak, WV, s, alpha, D.T, transpose=True)
+    Fs = Polyhedron(A=D, b=h)
+    return (Fs, dict(s=s, alpha=alpha, Ms=Ms, status=rc)) if return_info else Fs
+
+
+class InitialSetComputation:
+    """fields: B, N_pre_sam, N_sam_opt, nx, W, min_u_LV, max_u_LV, Xi_true_EV, Xi_true_LV (InitialSetComputation.m:28-43)"""
+    _calls = itertools.count()
+
+    def __init__(self, parameters_NEW, seed=0):
+        p = parameters_NEW
+        self.B = np.atleast_2d(np.asarray(p["B"], dtype=np.float64))
+        self.nx = int(p["nx"])
+        if self.B.shape[0] != self.nx:
+            self.B = self.B.T
+        self.N_pre_sam, self.N_sam_opt = int(p["N_pre_sam"]), int(p.get("N_sam_opt", 0))
+        self.W, self.W_A, self.W_b = p["W"], p["W"].A, p["W"].b
+        self.min_u_LV, self.max_u_LV = p["min_u_LV"], p["max_u_LV"]
+        self.Xi_true_EV, self.Xi_true_LV = p["Xi_true_EV"], p["Xi_true_LV"]
+        self.seed = seed
+        self.sampler = _abi.make_sampler(self.nx, self.B.shape[1], self.Xi_true_EV.A, self.Xi_true_EV.b,
+                                         self.Xi_true_EV.V, self.Xi_true_LV.A, self.Xi_true_LV.b, self.Xi_true_LV.V,
+                                         self.B, self.min_u_LV, self.max_u_LV)
+
+    def solve(self):
+        """[alpha_ini, v_ini, samplesinput] = obj.solve()  (:48-59); each call draws a fresh information set"""
+        set_id = next(InitialSetComputation._calls)
+        S, m, st = core.sample_information_sets(self.sampler, self.W_A, self.N_pre_sam, 1, self.seed, set0=set_id)
+        alpha, v, _, status = core.homothety_lp(self.W_A, self.W_b, m[0])
+        self.status = max(int(st[0]), status)
+        return alpha, v.reshape(-1, 1), S[0]
+
+    def solve_opt(self, samples_opt):
+        """[alpha_opt, v_opt] = obj.solve_opt(samples_opt)  (:61-67), samples nx x N"""
+        m = core.halfspace_max(self.W_A, np.asarray(samples_opt, dtype=np.float64))
+        alpha, v, _, self.status = core.homothety_lp(self.W_A, self.W_b, m)
+        return alpha, v.reshape(-1, 1)
+
+
+def _params_from_opts(o):
+    d = {k: o[k] for k in ("N", "nx", "nu", "nc", "Nu", "A", "B", "F", "G", "K", "Px", "Pc", "F_bar", "Psi", "Phi", "hs")
+         if k in o}
+    if "A" not in d:   # NominalRobustMPC's struct has no A/B/Phi: only the QP fields matter there
+        nx, nu = int(o["nx"]), int(o["nu"])
+        d["A"], d["B"] = np.zeros((nx, nx)), np.zeros((nx, nu))
+    if "Phi" not in d:
+        d["Phi"] = np.asarray(o["Psi"])[: int(o["nx"]), : int(o["nx"])]
+    for k in ("F", "G"):
+        if k not in d:
+            d[k] = np.zeros((int(o["nc"]), int(o["nx"] if k == "F" else o["nu"])))
+    d["S_A"], d["S_b"] = o["S"].A, o["S"].b
+    if "W" in o:
+        d["W_A"], d["W_b"] = o["W"].A, o["W"].b
+    else:
+        nx = int(o["nx"])
+        d["W_A"], d["W_b"] = np.vstack([np.eye(nx), -np.eye(nx)]), np.ones(2 * nx)
+    return d
+
+
+class UQRobustMPC:
+    """fields: N,nx,nu,nc,F,G,K,Px,Pc,F_bar,Psi,Phi,E,W,S,Nu,hs,Ps,num_half_space_S (UQRobustMPC.m:39-62)"""
+
+    def __init__(self, parameters):
+        self.opts = parameters
+        self.W, self.S = parameters["W"], parameters["S"]
+        self.nx, self.nu, self.nc = int(parameters["nx"]), int(parameters["nu"]), int(parameters["nc"])
+        self.ctx = core.Context(_params_from_opts(parameters))
+
+    def solve(self, x_k, alpha_before, v_before, w_new):
+        """[s_k_opt, u_k, alpha_k, v_k, hk, S_hat_star, W_hat] = obj.solve(x_k, alpha_before, v_before, w_new)  (:68-91)"""
+        o = self.ctx.step(np.ravel(x_k), alpha_before, np.ravel(v_before), np.ravel(w_new), uq_update=True)
+        self.status, self.active_set = int(o["status"]), o["active_set"][: int(o["n_active"])]
+        S_hat_star = Polyhedron(A=self.S.A, b=o["Sb_hat"])
+        W_hat = Polyhedron(A=self.W.A, b=o["Wb_hat"])
+        col = lambda a: np.asarray(a).reshape(-1, 1)
+        return col(o["s0"]), col(o["u"]), float(o["alpha"]), col(o["v"]), col(o["hk"]), S_hat_star, W_hat
+
+
+class NominalRobustMPC:
+    """fields: N,nx,nu,nc,Nu,Px,Pc,K,F_bar,Psi,E,S,hs (NominalRobustMPC.m:28-45)"""
+
+    def __init__(self, parameters):
+        self.nx = int(parameters["nx"])
+        self.ctx = core.Context(_params_from_opts(parameters))
+
+    def solve(self, x_k):
+        """[s_k_opt, u_k] = obj.solve(x_k)  (:47-52): the tube QP with the fixed S and hs"""
+        o = self.ctx.step(np.ravel(x_k), 1.0, np.zeros(self.nx), None, uq_update=False)
+        self.status = int(o["status"])
+        return np.asarray(o["s0"]).reshape(-1, 1), np.asarray(o["u"]).reshape(-1, 1)
+
+
+class ModelingCar:
+    """fields: A, B, min_u_LV, max_u_LV, Xi_true_EV, Xi_true_LV (ModelingCar.m:21-32).  Every call consumes the next
+    draw of this object's Philox stream (the reference consumes MATLAB's global rand)."""
+
+    def __init__(self, parameters, seed=0, stream=0):
+        p = parameters
+        self.A = np.asarray(p["A"], dtype=np.float64)
+        self.B = np.asarray(p["B"], dtype=np.float64).reshape(self.A.shape[0], -1)
+        self.Xi_true_EV, self.Xi_true_LV = p["Xi_true_EV"], p["Xi_true_LV"]
+        self.min_u_LV, self.max_u_LV = float(np.ravel(p["min_u_LV"])[0]), float(np.ravel(p["max_u_LV"])[0])
+        self.seed, self.stream, self._k = seed, stream, 0
+
+    def _sample(self, P, purpose):
+        lib = core.init()
+        A, b, V = fcol(P.A), fcol(P.b).ravel(), P.V
+        lo, hi = fcol(V.min(0)), fcol(V.max(0))
+        nx = A.shape[1]
+        out, st = np.zeros(nx), np.zeros(1, np.int32)
+        core._chk(lib.lbmpc_sample_polytope(dptr(A), dptr(b), A.shape[0], nx, dptr(lo), dptr(hi), 1, self.seed,
+                                            self.stream, self._k, purpose, 1000, dptr(out), iptr(st)),
+                  "lbmpc_sample_polytope")
+        return out.reshape(-1, 1)
+
+    def EVModeling(self, x_EV_k, u_EV_k):
+        """[xi_EV_k, x_EV_k_next] = EVModeling(x, u)  (:34-38)"""
+        xi = self._sample(self.Xi_true_EV, 5)
+        self._k += 1
+        return xi, self.A @ np.reshape(x_EV_k, (-1, 1)) + self.B @ np.reshape(u_EV_k, (-1, 1)) + xi
+
+    def LVModeling(self, x_LV_k):
+        """[xi_LV_k, x_LV_k_next] = LVModeling(x)  (:40-45)"""
+        xi = self._sample(self.Xi_true_LV, 3)
+        # u_LV: one uniform from the 1-row "polytope" [min_u, max_u] keeps the draw on the device stream
+        u = self._sample(Polyhedron(A=np.array([[1.0], [-1.0]]), b=np.array([self.max_u_LV, -self.min_u_LV]),
+                                    V=np.array([[self.min_u_LV], [self.max_u_LV]])), 4)
+        return xi, self.A @ np.reshape(x_LV_k, (-1, 1)) + xi + self.B * float(u[0, 0])
+
+
+def monte_carlo(opts_UQMPC, opts_Car, N_pre_sam, N_MC, K_N, x_RM_0, acc_bound, distance_error, seed=0, trial0=0,
+                record_trials=0):
+    """The Monte-Carlo loops of Cases_general/Case_3...:57-88, Case_4...:32-66, Case_5...:55-98 as ONE batched launch:
+    per trial, InitialSetComputation.solve() with N_pre_sam samples, then K_N closed-loop UQ-RMPC steps against the
+    sampled plant.  Returns dict(Infeasible_Index, alpha_K, v_K, W_Hat_Vol_final, State_RM, Control_EV, ...)."""
+    mpc = opts_UQMPC if isinstance(opts_UQMPC, UQRobustMPC) else UQRobustMPC(opts_UQMPC)
+    nx, nu = mpc.nx, mpc.nu
+    B = np.asarray(opts_Car["B"], dtype=np.float64).reshape(nx, nu)
+    smp = _abi.make_sampler(nx, nu, opts_Car["Xi_true_EV"].A, opts_Car["Xi_true_EV"].b, opts_Car["Xi_true_EV"].V,
+                            opts_Car["Xi_true_LV"].A, opts_Car["Xi_true_LV"].b, opts_Car["Xi_true_LV"].V, B,
+                            opts_Car["min_u_LV"], opts_Car["max_u_LV"])
+    o = mpc.ctx.mc_run(smp, trials=N_MC, steps=K_N, card_I0=N_pre_sam, seed=seed, x0=np.ravel(x_RM_0),
+                       acc_bound=acc_bound, distance_error=distance_error, trial0=trial0, traj_trials=record_trials)
+    volW = mpc.W.volume()
+    return dict(Infeasible_Index=o["infeasible"], status=o["status"], qp_iters=o["qp_iters"], alpha_ini=o["alpha0"],
+                alpha_K=o["alpha_final"], v_K=o["v_final"], W_Hat_Vol_final=o["alpha_final"] ** nx * volW,
+                State_RM=np.transpose(o["traj_x"], (0, 2, 1)), Control_EV=np.transpose(o["traj_u"], (0, 2, 1)),
+                Nominal_RM_State=np.transpose(o["traj_s0"], (0, 2, 1)), Alpha=o["traj_alpha"],
+                W_Hat_Vol=o["traj_alpha"] ** nx * volW)

@@ -269,6 +269,17 @@ int orc_sample_information_sets(const lbmpc_sampler* smp, const double* WA, int 
     return 0;
 }
 
+int orc_sample_polytope(const double* XA, const double* Xb, int nr, int nx, const double* lo, const double* hi,
+                        int64_t n, uint64_t seed, uint64_t stream, uint32_t index0, int purpose, int max_attempts,
+                        double* out, int* status_out) {
+    if (nx > LBMPC_MAX_NX || nr > LBMPC_MAX_NXI) return LBMPC_ERR_DIM;
+    for (int64_t i = 0; i < n; ++i) {
+        int cap = sample_polytope(XA, Xb, nr, lo, hi, nx, seed, stream, index0 + (uint32_t)i, (uint32_t)purpose, max_attempts, out + (size_t)i * nx);
+        if (status_out) status_out[i] = cap ? LBMPC_ST_SAMPLER_CAP : 0;
+    }
+    return 0;
+}
+
 /* Gaussian elimination with partial pivoting, n <= 8. returns 0 if singular */
 static int solve_dense(int n, double* M /* n x n row-major */, double* rhs) {
     for (int c = 0; c < n; ++c) {
