@@ -1,0 +1,165 @@
+// lbmpc_mex.cpp -- MEX gateway: MATLAB <-> liblbmpc_hip.so (include/lbmpc.h).
+//
+//   out = lbmpc_mex(cmd, args...)
+//
+// Built where MATLAB exists with
+//   mex -R2018a lbmpc_mex.cpp -I../../include -L../csrc -llbmpc_hip
+// (no mex.h in the build image: this file is compiled and exercised only on a MATLAB host; the same C ABI is
+// what tests/ drive through ctypes).  MATLAB owns every input mxArray (read-only via mxGetDoubles); outputs
+// are allocated with mxCreateDoubleMatrix and filled by the library.  Controller contexts are returned as
+// uint64 handles, freed by 'destroy' / mexAtExit; the MEX file stays locked while any context lives.
+#include <cstdint>
+#include <cstring>
+#include <set>
+#include <string>
+
+#include "lbmpc.h"
+#include "mex.h"
+
+static std::set<lbmpc_ctx*> g_live;
+static bool g_init = false;
+
+static void fail(const char* id, int rc) {
+    mexErrMsgIdAndTxt(id, "lbmpc error %d: %s", rc, lbmpc_last_error());
+}
+static void at_exit() {
+    for (lbmpc_ctx* c : g_live) lbmpc_destroy(c);
+    g_live.clear();
+}
+static const double* dbl(const mxArray* a) { return mxGetDoubles(a); }
+static int rows(const mxArray* a) { return (int)mxGetM(a); }
+static int cols(const mxArray* a) { return (int)mxGetN(a); }
+static const mxArray* field(const mxArray* s, const char* name) {
+    const mxArray* f = mxGetField(s, 0, name);
+    if (!f) mexErrMsgIdAndTxt("lbmpc:field", "missing field %s", name);
+    return f;
+}
+static int ifield(const mxArray* s, const char* name) { return (int)mxGetScalar(field(s, name)); }
+static lbmpc_ctx* handle(const mxArray* a) { return reinterpret_cast<lbmpc_ctx*>(*reinterpret_cast<uint64_t*>(mxGetData(a))); }
+
+static void fill_sampler(const mxArray* s, lbmpc_sampler* o) {
+    o->nx = ifield(s, "nx"); o->nu = ifield(s, "nu");
+    o->EV_A = dbl(field(s, "EV_A")); o->EV_b = dbl(field(s, "EV_b")); o->nEV = rows(field(s, "EV_A"));
+    o->EV_lo = dbl(field(s, "EV_lo")); o->EV_hi = dbl(field(s, "EV_hi"));
+    o->LV_A = dbl(field(s, "LV_A")); o->LV_b = dbl(field(s, "LV_b")); o->nLV = rows(field(s, "LV_A"));
+    o->LV_lo = dbl(field(s, "LV_lo")); o->LV_hi = dbl(field(s, "LV_hi"));
+    o->B = dbl(field(s, "B")); o->min_u_LV = dbl(field(s, "min_u_LV")); o->max_u_LV = dbl(field(s, "max_u_LV"));
+}
+
+void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    if (nrhs < 1 || !mxIsChar(prhs[0])) mexErrMsgIdAndTxt("lbmpc:usage", "lbmpc_mex(cmd, ...)");
+    char cmdbuf[64];
+    mxGetString(prhs[0], cmdbuf, sizeof cmdbuf);
+    const std::string cmd(cmdbuf);
+    if (!g_init) {
+        int rc = lbmpc_init(0);
+        if (rc) fail("lbmpc:init", rc);
+        mexAtExit(at_exit);
+        g_init = true;
+    }
+    if (cmd == "support_batch") {  // h = lbmpc_mex('support_batch', A, Vw, s, alpha, D, transpose)
+        const int nx = rows(prhs[1]);
+        const int64_t nd = cols(prhs[5]);
+        plhs[0] = mxCreateDoubleMatrix(nd, 1, mxREAL);
+        int rc = lbmpc_support_batch(dbl(prhs[1]), nx, dbl(prhs[2]), rows(prhs[2]), (int)mxGetScalar(prhs[3]),
+                                     mxGetScalar(prhs[4]), dbl(prhs[5]), nd, (int)mxGetScalar(prhs[6]), mxGetDoubles(plhs[0]));
+        if (rc < 0) fail("lbmpc:support_batch", rc);
+    } else if (cmd == "mrpi_s_alpha") {  // [s, alpha, Ms] = lbmpc_mex('mrpi_s_alpha', A, Vw, WA, Wb, Dirs, eps, mode)
+        int s = 0; double alpha = 0, Ms = 0;
+        int rc = lbmpc_mrpi_s_alpha(dbl(prhs[1]), rows(prhs[1]), dbl(prhs[2]), rows(prhs[2]), dbl(prhs[3]), dbl(prhs[4]),
+                                    rows(prhs[3]), dbl(prhs[5]), cols(prhs[5]), mxGetScalar(prhs[6]), (int)mxGetScalar(prhs[7]),
+                                    60, &s, &alpha, &Ms);
+        if (rc < 0) fail("lbmpc:mrpi_s_alpha", rc);
+        plhs[0] = mxCreateDoubleScalar(s);
+        if (nlhs > 1) plhs[1] = mxCreateDoubleScalar(alpha);
+        if (nlhs > 2) plhs[2] = mxCreateDoubleScalar(Ms);
+    } else if (cmd == "learn_set") {  // [alpha, v, status] = lbmpc_mex('learn_set', WA, Wb, samples)  samples nx x N
+        const int nW = rows(prhs[1]), nx = cols(prhs[1]);
+        double m[LBMPC_MAX_NW];
+        int rc = lbmpc_halfspace_max(dbl(prhs[1]), nW, nx, dbl(prhs[3]), cols(prhs[3]), 1, 0, m);
+        if (rc < 0) fail("lbmpc:halfspace_max", rc);
+        plhs[0] = mxCreateDoubleScalar(0);
+        mxArray* v = mxCreateDoubleMatrix(nx, 1, mxREAL);
+        int st = 0;
+        rc = lbmpc_homothety_lp(dbl(prhs[1]), dbl(prhs[2]), nW, nx, m, 1, LBMPC_TIE_CENTER, mxGetDoubles(plhs[0]), mxGetDoubles(v), nullptr, &st);
+        if (rc < 0) fail("lbmpc:homothety_lp", rc);
+        if (nlhs > 1) plhs[1] = v;
+        if (nlhs > 2) plhs[2] = mxCreateDoubleScalar(st);
+    } else if (cmd == "sample_sets") {  // [samples, m] = lbmpc_mex('sample_sets', sampler, WA, N, seed, set0)
+        lbmpc_sampler smp; fill_sampler(prhs[1], &smp);
+        const int nW = rows(prhs[2]);
+        const int64_t N = (int64_t)mxGetScalar(prhs[3]);
+        plhs[0] = mxCreateDoubleMatrix(smp.nx, N, mxREAL);
+        mxArray* m = mxCreateDoubleMatrix(nW, 1, mxREAL);
+        int rc = lbmpc_sample_information_sets(&smp, dbl(prhs[2]), nW, N, 1, (uint64_t)mxGetScalar(prhs[4]),
+                                               (uint64_t)mxGetScalar(prhs[5]), 100, mxGetDoubles(plhs[0]), mxGetDoubles(m), nullptr);
+        if (rc < 0) fail("lbmpc:sample_sets", rc);
+        if (nlhs > 1) plhs[1] = m;
+    } else if (cmd == "create") {  // h = lbmpc_mex('create', p)  p: struct with the lbmpc_params fields (A,b unpacked)
+        const mxArray* s = prhs[1];
+        lbmpc_params p;
+        p.nx = ifield(s, "nx"); p.nu = ifield(s, "nu"); p.N = ifield(s, "N"); p.nc = ifield(s, "nc"); p.Nu = ifield(s, "Nu");
+        p.nS = rows(field(s, "S_A")); p.nW = rows(field(s, "W_A"));
+        p.A = dbl(field(s, "A")); p.B = dbl(field(s, "B")); p.K = dbl(field(s, "K")); p.Phi = dbl(field(s, "Phi"));
+        p.Px = dbl(field(s, "Px")); p.Pc = dbl(field(s, "Pc")); p.F = dbl(field(s, "F")); p.G = dbl(field(s, "G"));
+        p.F_bar = dbl(field(s, "F_bar")); p.Psi = dbl(field(s, "Psi")); p.S_A = dbl(field(s, "S_A")); p.S_b = dbl(field(s, "S_b"));
+        p.W_A = dbl(field(s, "W_A")); p.W_b = dbl(field(s, "W_b")); p.hs = dbl(field(s, "hs"));
+        lbmpc_ctx* c = nullptr;
+        int rc = lbmpc_uqmpc_create(&p, &c);
+        if (rc) fail("lbmpc:create", rc);
+        g_live.insert(c);
+        if (g_live.size() == 1) mexLock();
+        plhs[0] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL);
+        *reinterpret_cast<uint64_t*>(mxGetData(plhs[0])) = reinterpret_cast<uint64_t>(c);
+    } else if (cmd == "destroy") {
+        lbmpc_ctx* c = handle(prhs[1]);
+        if (g_live.erase(c)) { lbmpc_destroy(c); if (g_live.empty()) mexUnlock(); }
+    } else if (cmd == "step") {
+        // [s0, u, alpha, v, hk, Sb_hat, Wb_hat, status] = lbmpc_mex('step', h, uq, dims, x, alpha_prev, v_prev, w_new)
+        lbmpc_ctx* c = handle(prhs[1]);
+        const int uq = (int)mxGetScalar(prhs[2]);
+        const double* dims = dbl(prhs[3]);  // [nx nu nc nS nW]
+        const int nx = (int)dims[0], nu = (int)dims[1], nc = (int)dims[2], nS = (int)dims[3], nW = (int)dims[4];
+        plhs[0] = mxCreateDoubleMatrix(nx, 1, mxREAL);
+        mxArray* u = mxCreateDoubleMatrix(nu, 1, mxREAL); mxArray* al = mxCreateDoubleScalar(0);
+        mxArray* v = mxCreateDoubleMatrix(nx, 1, mxREAL); mxArray* hk = mxCreateDoubleMatrix(nc, 1, mxREAL);
+        mxArray* Sb = mxCreateDoubleMatrix(nS, 1, mxREAL); mxArray* Wb = mxCreateDoubleMatrix(nW, 1, mxREAL);
+        int st = 0;
+        const double ap = mxGetScalar(prhs[5]);
+        int rc = lbmpc_uqmpc_step(c, 1, uq, dbl(prhs[4]), &ap, dbl(prhs[6]), uq ? dbl(prhs[7]) : nullptr, mxGetDoubles(plhs[0]),
+                                  nullptr, mxGetDoubles(u), mxGetDoubles(al), mxGetDoubles(v), mxGetDoubles(hk), mxGetDoubles(Sb),
+                                  mxGetDoubles(Wb), &st, nullptr, nullptr, nullptr);
+        if (rc < 0) fail("lbmpc:step", rc);
+        // numerical statuses do not throw: the reference has none (UQRobustMPC.m:156-158); warn and return the iterate
+        if (st) mexWarnMsgIdAndTxt("lbmpc:status", "UQ-RMPC step status %d (1 QP infeasible, 2 LP infeasible, 3 iteration cap)", st);
+        mxArray* outs[] = {u, al, v, hk, Sb, Wb, mxCreateDoubleScalar(st)};
+        for (int i = 1; i < nlhs && i <= 7; ++i) plhs[i] = outs[i - 1];
+    } else if (cmd == "mc_run") {
+        // R = lbmpc_mex('mc_run', h, sampler, cfg)  cfg: trials, steps, card_I0, seed, x0, acc_bound, distance_error, trial0
+        lbmpc_ctx* c = handle(prhs[1]);
+        lbmpc_sampler smp; fill_sampler(prhs[2], &smp);
+        const mxArray* s = prhs[3];
+        lbmpc_mc_cfg cfg;
+        std::memset(&cfg, 0, sizeof cfg);
+        cfg.trials = (int64_t)mxGetScalar(field(s, "trials")); cfg.trial0 = (int64_t)mxGetScalar(field(s, "trial0"));
+        cfg.steps = ifield(s, "steps"); cfg.card_I0 = ifield(s, "card_I0"); cfg.seed = (uint64_t)mxGetScalar(field(s, "seed"));
+        cfg.x0 = dbl(field(s, "x0")); cfg.acc_bound = mxGetScalar(field(s, "acc_bound"));
+        cfg.distance_error = mxGetScalar(field(s, "distance_error")); cfg.sampler_max_attempts = 1000;
+        const char* names[] = {"Infeasible_Index", "status", "alpha_K", "v_K"};
+        plhs[0] = mxCreateStructMatrix(1, 1, 4, names);
+        mxArray* inf = mxCreateNumericMatrix(cfg.trials, 1, mxINT32_CLASS, mxREAL);
+        mxArray* st = mxCreateNumericMatrix(cfg.trials, 1, mxINT32_CLASS, mxREAL);
+        mxArray* aK = mxCreateDoubleMatrix(cfg.trials, 1, mxREAL);
+        mxArray* vK = mxCreateDoubleMatrix(smp.nx, cfg.trials, mxREAL);
+        lbmpc_mc_out out;
+        std::memset(&out, 0, sizeof out);
+        out.infeasible = (int32_t*)mxGetData(inf); out.status = (int32_t*)mxGetData(st);
+        out.alpha_final = mxGetDoubles(aK); out.v_final = mxGetDoubles(vK);
+        int rc = lbmpc_mc_run(c, &smp, &cfg, &out);
+        if (rc < 0) fail("lbmpc:mc_run", rc);
+        mxSetField(plhs[0], 0, names[0], inf); mxSetField(plhs[0], 0, names[1], st);
+        mxSetField(plhs[0], 0, names[2], aK); mxSetField(plhs[0], 0, names[3], vK);
+    } else {
+        mexErrMsgIdAndTxt("lbmpc:usage", "unknown command %s", cmdbuf);
+    }
+}
