@@ -54,35 +54,74 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane /* wave-un
     return b.d;
 }
 
+// whole-wave rotate by one lane (DPP wave_rol:1): lane l receives lane (l+1) & 63
+__device__ __forceinline__ double wave_rol1_f64(double v) {
+    union { double d; int i[2]; } a, b;
+    a.d = v;
+    b.i[0] = __builtin_amdgcn_update_dpp(a.i[0], a.i[0], 0x134, 0xf, 0xf, false);
+    b.i[1] = __builtin_amdgcn_update_dpp(a.i[1], a.i[1], 0x134, 0xf, 0xf, false);
+    return b.d;
+}
+
+// DPP lane exchanges inside a 16-lane row: CTRL 0xB1 = quad_perm[1,0,3,2] (lane^1), 0x4E = quad_perm[2,3,0,1]
+// (lane^2), 0x141 = row_half_mirror (7-i within 8), 0x140 = row_mirror (15-i within 16).  All lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    union { double d; int i[2]; } a, b;
+    a.d = v;
+    b.i[0] = dpp_i32<CTRL>(a.i[0]);
+    b.i[1] = dpp_i32<CTRL>(a.i[1]);
+    return b.d;
+}
+
+// Wave-wide min / max (every lane gets the result): 4 DPP steps reduce each 16-lane row, the 4 row results are
+// combined through readlane.  No LDS traffic (the __shfl_xor forms go through ds_bpermute).
+__device__ __forceinline__ double wave_min(double v) {
+    v = __builtin_fmin(v, dpp_f64<0xB1>(v));
+    v = __builtin_fmin(v, dpp_f64<0x4E>(v));
+    v = __builtin_fmin(v, dpp_f64<0x141>(v));
+    v = __builtin_fmin(v, dpp_f64<0x140>(v));
+    return __builtin_fmin(__builtin_fmin(readlane_f64(v, 0), readlane_f64(v, 16)),
+                          __builtin_fmin(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        double o = __shfl_xor(v, off, LB_WAVE);
-        v = o > v ? o : v;
-    }
-    return v;
+    v = __builtin_fmax(v, dpp_f64<0xB1>(v));
+    v = __builtin_fmax(v, dpp_f64<0x4E>(v));
+    v = __builtin_fmax(v, dpp_f64<0x141>(v));
+    v = __builtin_fmax(v, dpp_f64<0x140>(v));
+    return __builtin_fmax(__builtin_fmax(readlane_f64(v, 0), readlane_f64(v, 16)),
+                          __builtin_fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+    int o;
+    o = dpp_i32<0xB1>(v); v = o < v ? o : v;
+    o = dpp_i32<0x4E>(v); v = o < v ? o : v;
+    o = dpp_i32<0x141>(v); v = o < v ? o : v;
+    o = dpp_i32<0x140>(v); v = o < v ? o : v;
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    const int ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
 }
 
 // (value, index) arg-min with ties to the lowest index; every lane gets the result.
 __device__ __forceinline__ void wave_argmin(double& v, int& idx) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        double ov = __shfl_xor(v, off, LB_WAVE);
-        int oi = __shfl_xor(idx, off, LB_WAVE);
-        bool take = (ov < v) || (ov == v && oi < idx);
-        v = take ? ov : v;
-        idx = take ? oi : idx;
-    }
+    const double best = wave_min(v);
+    idx = wave_min_i32(v == best ? idx : 0x7fffffff);
+    v = best;
 }
 
 // ---- RNG: Philox4x32-10, bit-identical to oracle/lbmpc_oracle.c ------------------------------
 __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-        uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
-        uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
-        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        // one 32x32->64 product per multiplier (v_mad_u64_u32) instead of separate mul_hi / mul_lo
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }

@@ -32,7 +32,7 @@ namespace lbmpc {
 #define NZMAX LBMPC_MAX_NZ
 
 struct CtxDev {
-    int nx, nu, N, nc, Nu, nS, nW, nz, nH, RL, nzp;
+    int nx, nu, N, nc, Nu, nS, nW, nz, nH, RL, nzp, nSp;  // nSp: S rows padded to a multiple of 8 (never-active pad rows)
     double A[LBMPC_MAX_NX * LBMPC_MAX_NX];    // row-major
     double B[LBMPC_MAX_NX * LBMPC_MAX_NU];    // row-major nx x nu
     double K[LBMPC_MAX_NU * LBMPC_MAX_NX];    // row-major nu x nx
@@ -40,7 +40,7 @@ struct CtxDev {
     double FcT[LBMPC_MAX_NC * LBMPC_MAX_NX];  // (F+GK) T row-major
     double hs[LBMPC_MAX_NC];
     BoxW box;
-    const double* Srow;  // nS x RL : [S_b[j], S_A[j,0..nx-1], pad]
+    const double* Srow;  // nSp x RL : [S_b[j], S_A[j,0..nx-1]], RL = nx + 1
     const double* Hm;    // nH x nzp: rows of F_bar Psi^i, i = 0..Nu
     const double* Ginv;  // nz x nz : (2 blkdiag(Px,Pc))^-1
 };
@@ -62,198 +62,13 @@ struct LdsView {
     const double* Hm;
     const double* Ginv;
 };
-struct WsView {  // per-wave solver workspace in LDS
-    double *z, *g, *rhs, *omh, *Wm, *L;
-    int* act;
-};
-__host__ __device__ inline int ws_doubles(int nz) { return 72 + 2 * nz * nz; }
-__device__ __forceinline__ WsView ws_view(double* base, int nz) {
-    WsView w;
-    w.z = base; w.g = base + 16; w.rhs = base + 32; w.omh = base + 48;
-    w.act = reinterpret_cast<int*>(base + 64);
-    w.Wm = base + 72; w.L = base + 72 + nz * nz;
-    return w;
-}
+__host__ __device__ inline int ws_doubles(int) { return 4 * 48; }  // GWS_PER_WAVE: four row slots per wave
 
-// coefficient k of QP row p (c_p of c_p.z <= d_p): S rows are [-S_A[j,:], 0], H rows F_bar Psi^i
-__device__ __forceinline__ double row_coef(const CtxDev* __restrict__ C, const LdsView& L, int p, int k) {
-    if (p < C->nS) return k < C->nx ? -L.Srow[p * C->RL + 1 + k] : 0.0;
-    return L.Hm[(p - C->nS) * C->nzp + k];
-}
-// c_p . w for a length-nz LDS vector w (fma chain from 0, ascending k; zero coefficients skipped,
-// which is exact)
-__device__ __forceinline__ double row_dot(const CtxDev* __restrict__ C, const LdsView& L, int p, const double* w) {
-    double acc = 0.0;
-    if (p < C->nS) {
-        for (int k = 0; k < C->nx; ++k) acc = fma(-L.Srow[p * C->RL + 1 + k], w[k], acc);
-    } else {
-        const double* h = L.Hm + (p - C->nS) * C->nzp;
-        for (int k = 0; k < C->nz; ++k) acc = fma(h[k], w[k], acc);
-    }
-    return acc;
-}
+}  // namespace lbmpc
 
-// Append row `a` (constraint pa, wave-uniform) to the Cholesky factor of M = C_A Ginv C_A'.
-// Lane b holds M[a][b] = c_pa . Wm[b]; the row solve L y = M[a][0..a) is a column sweep (ascending k,
-// the oracle's order), y_k broadcast by readlane; lane a accumulates the diagonal.
-__device__ __forceinline__ void chol_append(const CtxDev* __restrict__ C, const LdsView& L, const WsView& ws,
-                                            int a, int pa, int lane) {
-    const int nz = C->nz;
-    double acc = 0.0;
-    if (lane <= a) acc = row_dot(C, L, pa, ws.Wm + lane * nz);
-    for (int k = 0; k < a; ++k) {
-        const double yk = readlane_f64(acc, k) / ws.L[k * nz + k];
-        if (lane == k) acc = yk;
-        else if (lane > k && lane < a) acc = fma(-yk, ws.L[lane * nz + k], acc);
-        else if (lane == a) acc = fma(-yk, yk, acc);
-    }
-    if (lane == a) acc = sqrt(acc > 0.0 ? acc : 0.0);
-    if (lane <= a) ws.L[a * nz + lane] = acc;
-    wave_sync();
-}
+#include "qp_group.hpp"
 
-// Wave-cooperative Goldfarb-Idnani dual active-set solve of
-//   min z'Pz  s.t.  alpha S_b + S_A (q + s0) >= 0,  (1-h) - H z >= 0      (UQRobustMPC.m:149-155)
-// from z = 0.  alpha, q[] wave-uniform; ws.omh[] holds 1-h_k.  Result: ws.z, ws.act[0..nact).
-// Lane a carries active constraint a (row id, multiplier u_a, r_a); lane k < nz carries z_k, g_k.
-// Same arithmetic, operation order and tie rules as the oracle's qp_solve.
-template <int NX>
-__device__ __forceinline__ int coop_qp_solve(const CtxDev* __restrict__ C, const LdsView& L, const WsView& ws,
-                                             double alpha, const double* q, int& nact_out, int& iters_out) {
-    const int lane = lane_id();
-    const int nz = C->nz, nS = C->nS, nH = C->nH, nc = C->nc, RL = C->RL, nzp = C->nzp;
-    int nq = 0, iters = 0, status = 0;
-    uint64_t actS = 0, actH = 0;  // bit i: my i-th S row (lane + 64 i) / H row is active
-    double my_u = 0.0, my_z = 0.0;
-    int my_act = -1;
-    if (lane < NZMAX) ws.z[lane] = 0.0;
-    wave_sync();
-    for (;;) {
-        // Step 1: most violated row at the current z
-        int p;
-        double sp;
-        {
-            double zr[NZMAX], e[NX];
-#pragma unroll
-            for (int k = 0; k < NZMAX; ++k) zr[k] = (k < nz) ? ws.z[k] : 0.0;
-#pragma unroll
-            for (int k = 0; k < NX; ++k) e[k] = q[k] + zr[k];
-            double best = -QP_TOL_VIOL;
-            int bj = 0x7fffffff;
-            int i = 0;
-            for (int j = lane; j < nS; j += LB_WAVE, ++i) {
-                const double* row = L.Srow + j * RL;
-                double acc = alpha * row[0];
-#pragma unroll
-                for (int k = 0; k < NX; ++k) acc = fma(row[1 + k], e[k], acc);
-                if (!((actS >> i) & 1) && acc < best) { best = acc; bj = j; }
-            }
-            int r = lane % nc;
-            const int rstep = LB_WAVE % nc;
-            i = 0;
-            for (int h = lane; h < nH; h += LB_WAVE, ++i) {
-                const double* row = L.Hm + h * nzp;
-                double acc = ws.omh[r];
-#pragma unroll
-                for (int k = 0; k < NZMAX; ++k)
-                    if (k < nz) acc = fma(-row[k], zr[k], acc);
-                if (!((actH >> i) & 1) && acc < best) { best = acc; bj = nS + h; }
-                r += rstep;
-                if (r >= nc) r -= nc;
-            }
-            wave_argmin(best, bj);
-            if (bj == 0x7fffffff) break;  // optimal
-            p = bj; sp = best;
-        }
-        // g = Ginv c_p ; cg = c_p . g
-        double my_g = 0.0;
-        if (lane < nz) {
-            double acc = 0.0;
-            if (p < nS) { for (int k = 0; k < NX; ++k) acc = fma(L.Ginv[lane * nz + k], -L.Srow[p * RL + 1 + k], acc); }
-            else { const double* h = L.Hm + (p - nS) * nzp; for (int k = 0; k < nz; ++k) acc = fma(L.Ginv[lane * nz + k], h[k], acc); }
-            ws.g[lane] = my_g = acc;
-        }
-        wave_sync();
-        const double cg = row_dot(C, L, p, ws.g);
-        if (lane == nq) my_u = 0.0;
-        // Step 2
-        for (;;) {
-            if (++iters > QP_MAX_ITERS) { status = LBMPC_ST_ITER_CAP; goto done; }
-            double my_r = 0.0, my_rhs = 0.0, delta = cg;
-            if (nq > 0) {
-                if (lane < nq) my_rhs = row_dot(C, L, my_act, ws.g);
-                double acc = my_rhs;
-                for (int k = 0; k < nq; ++k) {  // L y = rhs
-                    const double yk = readlane_f64(acc, k) / ws.L[k * nz + k];
-                    if (lane == k) acc = yk;
-                    else if (lane > k && lane < nq) acc = fma(-ws.L[lane * nz + k], yk, acc);
-                }
-                for (int k = nq - 1; k >= 0; --k) {  // L' r = y
-                    const double rk = readlane_f64(acc, k) / ws.L[k * nz + k];
-                    if (lane == k) acc = rk;
-                    else if (lane < k) acc = fma(-ws.L[k * nz + lane], rk, acc);
-                }
-                my_r = (lane < nq) ? acc : 0.0;
-                for (int a = 0; a < nq; ++a) delta = fma(-readlane_f64(my_rhs, a), readlane_f64(my_r, a), delta);
-            }
-            // primal direction, component `lane`: zd = -(g - Wm' r)
-            double zacc = my_g;
-            for (int a = 0; a < nq; ++a) {
-                const double ra = readlane_f64(my_r, a);
-                if (lane < nz) zacc = fma(-ws.Wm[a * nz + lane], ra, zacc);
-            }
-            const double zd = -zacc;
-            const bool dependent = (nq >= nz) || !(delta > QP_TOL_DEP * cg);
-            const double rmax = wave_max((lane < nq) ? fabs(my_r) : 0.0);
-            double t1 = LB_INF;
-            int kdrop = 0x7fffffff;
-            if (lane < nq && my_r > QP_TOL_R * rmax) { t1 = my_u / my_r; kdrop = lane; }
-            wave_argmin(t1, kdrop);
-            const double t2 = dependent ? LB_INF : -sp / delta;
-            const double t = t1 < t2 ? t1 : t2;
-#ifdef LBMPC_TRACE
-            if (lane == 0) printf("GPU it=%d p=%d sp=%.17g nq=%d cg=%.17g delta=%.17g t1=%.17g t2=%.17g kdrop=%d dep=%d r0=%.17g u0=%.17g\n", iters, p, sp, nq, cg, delta, t1, t2, kdrop == 0x7fffffff ? -1 : kdrop, (int)dependent, my_r, my_u);
-#endif
-            if (t == LB_INF) { status = LBMPC_ST_QP_INFEASIBLE; goto done; }
-            if (lane < nq) my_u = fma(-t, my_r, my_u);
-            if (lane == nq) my_u += t;
-            if (!dependent) {
-                if (lane < nz) { my_z = fma(t, zd, my_z); ws.z[lane] = my_z; }
-                sp = fma(t, delta, sp);
-            }
-            wave_sync();
-            if (!dependent && t2 <= t1) {
-                // full step: constraint p joins the active set
-                if (lane < nz) ws.Wm[nq * nz + lane] = my_g;
-                if (lane == nq) my_act = p;
-                wave_sync();
-                chol_append(C, L, ws, nq, p, lane);
-                if (p < nS) { if ((p & 63) == lane) actS |= 1ull << (p >> 6); }
-                else { int h = p - nS; if ((h & 63) == lane) actH |= 1ull << (h >> 6); }
-                nq++;
-                break;
-            }
-            // drop active constraint kdrop, stay in step 2
-            const int pd = __builtin_amdgcn_readlane(my_act, kdrop);
-            if (pd < nS) { if ((pd & 63) == lane) actS &= ~(1ull << (pd >> 6)); }
-            else { int h = pd - nS; if ((h & 63) == lane) actH &= ~(1ull << (h >> 6)); }
-            const int nxt_act = __shfl_down(my_act, 1, LB_WAVE);
-            const double nxt_u = __shfl_down(my_u, 1, LB_WAVE);
-            if (lane >= kdrop && lane < nq) { my_act = nxt_act; my_u = nxt_u; }
-            if (lane < nz)
-                for (int a = kdrop; a < nq - 1; ++a) ws.Wm[a * nz + lane] = ws.Wm[(a + 1) * nz + lane];
-            nq--;
-            wave_sync();
-            for (int a = kdrop; a < nq; ++a) chol_append(C, L, ws, a, __builtin_amdgcn_readlane(my_act, a), lane);
-        }
-    }
-done:
-    if (lane < nq) ws.act[lane] = my_act;
-    wave_sync();
-    nact_out = nq;
-    iters_out = iters;
-    return status;
-}
+namespace lbmpc {
 
 // ---- lane-per-trial pieces ----------------------------------------------------------------------
 
@@ -328,79 +143,120 @@ __device__ __forceinline__ double hk_value(const CtxDev* __restrict__ C, double 
 // exactly 1-h_k[r] at z = 0.  Only "is any row violated" is needed here: the pivot itself is found by
 // the cooperative solver, which recomputes the same values.
 template <int NX, int T>
+__device__ __forceinline__ void first_pass_eval(const double2* cur, const double* alpha, const double (*q)[NX], double* mn) {
+    constexpr int RLc = NX + 1, CH = 4 * RLc / 2;
+    double cf[4 * RLc];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { cf[2 * i] = cur[i].x; cf[2 * i + 1] = cur[i].y; }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        double acc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc[r] = alpha[t] * cf[r * RLc];
+#pragma unroll
+            for (int k = 0; k < NX; ++k) acc[r] = fma(cf[r * RLc + 1 + k], q[t][k], acc[r]);
+        }
+        mn[t] = __builtin_fmin(mn[t], __builtin_fmin(__builtin_fmin(acc[0], acc[1]), __builtin_fmin(acc[2], acc[3])));
+    }
+}
+
+template <int NX, int T>
 __device__ __forceinline__ void first_pass(const CtxDev* __restrict__ C, const LdsView& L, const double* alpha,
                                            const double (*q)[NX], const double* min_omh, bool* need) {
+    constexpr int RLc = NX + 1;        // == C->RL
+    constexpr int CH = 4 * RLc / 2;    // double2 loads per chunk of 4 rows
     double mn[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) mn[t] = min_omh[t];
-    const int nS = C->nS;
-    constexpr int RLc = (NX + 2) & ~1;  // == C->RL
-    const double2* row = reinterpret_cast<const double2*>(L.Srow);
-#pragma unroll 4
-    for (int j = 0; j < nS; ++j, row += RLc / 2) {
-        double c[RLc];
+    const int nch = C->nSp >> 2;       // even: nSp is a multiple of 8
+    const double2* p = reinterpret_cast<const double2*>(L.Srow);
+    double2 bufA[CH], bufB[CH];
 #pragma unroll
-        for (int i = 0; i < RLc / 2; ++i) { double2 t2 = row[i]; c[2 * i] = t2.x; c[2 * i + 1] = t2.y; }
+    for (int i = 0; i < CH; ++i) bufA[i] = p[i];
+    // ping-pong: the next chunk of 4 rows is in flight while the current one is evaluated
+    for (int c = 0; c < nch; c += 2) {
+        const double2* pb = p + (size_t)(c + 1) * CH;
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            double acc = alpha[t] * c[0];
+        for (int i = 0; i < CH; ++i) bufB[i] = pb[i];
+        __builtin_amdgcn_sched_barrier(0);
+        first_pass_eval<NX, T>(bufA, alpha, q, mn);
+        const double2* pa = p + (size_t)(c + 2 < nch ? c + 2 : 0) * CH;
 #pragma unroll
-            for (int k = 0; k < NX; ++k) acc = fma(c[1 + k], q[t][k], acc);
-            mn[t] = acc < mn[t] ? acc : mn[t];
-        }
+        for (int i = 0; i < CH; ++i) bufA[i] = pa[i];
+        __builtin_amdgcn_sched_barrier(0);
+        first_pass_eval<NX, T>(bufB, alpha, q, mn);
     }
 #pragma unroll
     for (int t = 0; t < T; ++t) need[t] = mn[t] < -QP_TOL_VIOL;
 }
 
 __device__ __forceinline__ void stage_constants(const CtxDev* __restrict__ C, double* lds) {
-    const int nS_RL = C->nS * C->RL, nH_nzp = C->nH * C->nzp, nzz = C->nz * C->nz;
+    const int nS_RL = C->nSp * C->RL, nH_nzp = C->nH * C->nzp, nzz = C->nz * C->nz;
     for (int i = threadIdx.x; i < nS_RL; i += blockDim.x) lds[i] = C->Srow[i];
     for (int i = threadIdx.x; i < nH_nzp; i += blockDim.x) lds[nS_RL + i] = C->Hm[i];
     for (int i = threadIdx.x; i < nzz; i += blockDim.x) lds[nS_RL + nH_nzp + i] = C->Ginv[i];
     __syncthreads();
 }
 
-// Solve the QPs of the lanes flagged in `need` one after the other, cooperatively.
-// Owner lane receives: z_head[0..NX) = s0, z_u[0..nu) = c(1:nu), status, iters.
+// Solve the QPs of the lanes flagged in `need`, four at a time (one per 16-lane row of the wave).
+// Owner lane receives: s0 = z[0..NX), c0 = z[NX..NX+nu), status, iters (+ optional active set / full c).
 template <int NX>
-__device__ __forceinline__ void solve_flagged(const CtxDev* __restrict__ C, const LdsView& L, const WsView& ws,
+__device__ __forceinline__ void solve_flagged(const CtxDev* __restrict__ C, const LdsView& L, double* wws /* wave slot */,
                                               bool need, double alpha, const double* v, const double* q,
                                               double* s0, double* c0, int& status, int& iters,
                                               int* nact_out, int* act_out /* NZMAX, sorted, or null */,
                                               double* c_full /* nz-NX or null */) {
-    const int lane = lane_id();
+    const int lane = lane_id(), grp = lane >> 4;
     uint64_t mask = __builtin_amdgcn_ballot_w64(need);
     while (mask) {
-        const int src = __builtin_ctzll(mask);
-        mask &= mask - 1;
-        double qa[NX];
-        const double a_u = readlane_f64(alpha, src);
+        int src[4];
 #pragma unroll
-        for (int k = 0; k < NX; ++k) qa[k] = readlane_f64(q[k], src);
-        if (lane == src)
-            for (int r = 0; r < C->nc; ++r) ws.omh[r] = 1.0 - hk_value<NX>(C, alpha, v, r);
+        for (int g = 0; g < 4; ++g) {
+            src[g] = mask ? (int)__builtin_ctzll(mask) : -1;
+            if (mask) mask &= mask - 1;
+        }
+        // row g works on the problem of lane src[g]
+        double a_g = 0.0, q_g[NX];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) q_g[k] = 0.0;
+        int mygrp = -1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int sl = src[g] < 0 ? 0 : src[g];
+            const double ar = readlane_f64(alpha, sl);
+            a_g = grp == g ? ar : a_g;
+#pragma unroll
+            for (int k = 0; k < NX; ++k) { const double qr = readlane_f64(q[k], sl); q_g[k] = grp == g ? qr : q_g[k]; }
+            if (lane == src[g]) mygrp = g;
+        }
+        const bool live = (grp == 0 ? src[0] : grp == 1 ? src[1] : grp == 2 ? src[2] : src[3]) >= 0;
+        if (mygrp >= 0)
+            for (int r = 0; r < C->nc; ++r) wws[mygrp * GWS_DOUBLES + r] = 1.0 - hk_value<NX>(C, alpha, v, r);
         wave_sync();
-        int nact = 0, it = 0;
-        const int st = coop_qp_solve<NX>(C, L, ws, a_u, qa, nact, it);
+        group_qp_solve<NX>(C, L, wws + grp * GWS_DOUBLES, live, a_g, q_g);
         wave_sync();
-        if (lane == src) {
+        if (mygrp >= 0) {
+            const double* gw = wws + mygrp * GWS_DOUBLES;
+            const int* gi = reinterpret_cast<const int*>(gw + 40);
 #pragma unroll
-            for (int k = 0; k < NX; ++k) s0[k] = ws.z[k];
+            for (int k = 0; k < NX; ++k) s0[k] = gw[16 + k];
 #pragma unroll
-            for (int j = 0; j < LBMPC_MAX_NU; ++j) if (j < C->nu) c0[j] = ws.z[NX + j];
+            for (int j = 0; j < LBMPC_MAX_NU; ++j) if (j < C->nu) c0[j] = gw[16 + NX + j];
+            const int st = gi[0], nact = gi[2];
             status = st > status ? st : status;
-            iters += it;
+            iters += gi[1];
             if (nact_out) *nact_out = nact;
             if (act_out) {
+                const int* ga = reinterpret_cast<const int*>(gw + 32);
                 for (int a = 0; a < NZMAX; ++a) act_out[a] = -1;
                 for (int a = 0; a < nact; ++a) {  // ascending insertion
-                    int val = ws.act[a], pos = a;
+                    int val = ga[a], pos = a;
                     while (pos > 0 && act_out[pos - 1] > val) { act_out[pos] = act_out[pos - 1]; --pos; }
                     act_out[pos] = val;
                 }
             }
-            if (c_full) for (int k = NX; k < C->nz; ++k) c_full[k - NX] = ws.z[k];
+            if (c_full) for (int k = NX; k < C->nz; ++k) c_full[k - NX] = gw[16 + k];
         }
         wave_sync();
     }
@@ -418,10 +274,10 @@ __global__ __launch_bounds__(256) void uqmpc_step_kernel(const CtxDev* __restric
     extern __shared__ double lds[];
     stage_constants(C, lds);
     LdsView L;
-    L.Srow = lds; L.Hm = lds + C->nS * C->RL; L.Ginv = L.Hm + C->nH * C->nzp;
+    L.Srow = lds; L.Hm = lds + C->nSp * C->RL; L.Ginv = L.Hm + C->nH * C->nzp;
     const int wave = threadIdx.x / LB_WAVE, nwaves = blockDim.x / LB_WAVE, lane = lane_id();
     const int nz = C->nz, ncv = nz - NX;
-    WsView ws = ws_view(lds + C->nS * C->RL + C->nH * C->nzp + nz * nz + wave * ws_doubles(nz), nz);
+    double* ws = lds + C->nSp * C->RL + C->nH * C->nzp + nz * nz + wave * ws_doubles(nz);
     for (int64_t base = ((int64_t)blockIdx.x * nwaves + wave) * LB_WAVE; base < batch;
          base += (int64_t)gridDim.x * nwaves * LB_WAVE) {
         const int64_t b = base + lane;
@@ -500,16 +356,29 @@ struct McArgs {
     lbmpc_mc_out out;
 };
 
+#ifdef LBMPC_PROFILE
+__device__ unsigned long long lbmpc_prof[16];
+#define PROF_T(var) const long long var = clock64()
+#define PROF_ADD(slot, t0, t1) prof[slot] += (t1) - (t0)
+#else
+#define PROF_T(var)
+#define PROF_ADD(slot, t0, t1)
+#endif
+
 template <int NX, int T>
 __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, SamplerDev smp, McArgs a) {
     extern __shared__ double lds[];
     stage_constants(C, lds);
     LdsView L;
-    L.Srow = lds; L.Hm = lds + C->nS * C->RL; L.Ginv = L.Hm + C->nH * C->nzp;
+    L.Srow = lds; L.Hm = lds + C->nSp * C->RL; L.Ginv = L.Hm + C->nH * C->nzp;
     const int wave = threadIdx.x / LB_WAVE, nwaves = blockDim.x / LB_WAVE, lane = lane_id();
     const int nz = C->nz, nu = C->nu, K = a.steps;
-    WsView ws = ws_view(lds + C->nS * C->RL + C->nH * C->nzp + nz * nz + wave * ws_doubles(nz), nz);
+    double* ws = lds + C->nSp * C->RL + C->nH * C->nzp + nz * nz + wave * ws_doubles(nz);
     const SamplerDev* S = &smp;
+#ifdef LBMPC_PROFILE
+    long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    PROF_T(pk0);
+#endif
     for (int64_t base = ((int64_t)blockIdx.x * nwaves + wave) * (LB_WAVE * T); base < a.trials;
          base += (int64_t)gridDim.x * nwaves * (LB_WAVE * T)) {
         int64_t tl[T];      // local trial index
@@ -557,6 +426,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
             double q[T][NX], xi_lv[T][NX], Bul[T][NX], momh[T];
             int aomh[T];
             bool need[T];
+            PROF_T(p0);
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 // LVModeling first (Case_3...:58; ModelingCar.m:42-43)
@@ -568,7 +438,10 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
                 status[t] = st > status[t] ? st : status[t];
                 tighten<NX>(C, alpha[t], v[t], x[t], q[t], momh[t], aomh[t]);
             }
+            PROF_T(p1);
             first_pass<NX, T>(C, L, alpha, q, momh, need);
+            PROF_T(p2);
+            PROF_ADD(0, p0, p1); PROF_ADD(1, p1, p2);
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 double s0[NX], c0[LBMPC_MAX_NU], u[LBMPC_MAX_NU];
@@ -576,8 +449,15 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
                 for (int i = 0; i < NX; ++i) s0[i] = 0.0;
 #pragma unroll
                 for (int j = 0; j < LBMPC_MAX_NU; ++j) c0[j] = 0.0;
+                PROF_T(p3);
+#ifdef LBMPC_PROFILE
+                prof[4] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid[t] && need[t]));
+                prof[5] += (__builtin_popcountll(__builtin_amdgcn_ballot_w64(valid[t] && need[t])) + 3) >> 2;
+#endif
                 solve_flagged<NX>(C, L, ws, valid[t] && need[t], alpha[t], v[t], q[t], s0, c0,
                                   status[t], iters[t], nullptr, nullptr, nullptr);
+                PROF_T(p4);
+                PROF_ADD(2, p3, p4);
                 // u = K x + c(1:nu); EVModeling (ModelingCar.m:36-37); relative dynamics
                 double xi_ev[NX], Ax[NX], Bu[NX], xn[NX];
 #pragma unroll
@@ -620,6 +500,8 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
                     if (a.out.traj_alpha) a.out.traj_alpha[tl[t] * (K + 1) + k + 1] = alpha[t];
                     if (a.out.traj_s0) for (int i = 0; i < NX; ++i) a.out.traj_s0[(tl[t] * K + k) * NX + i] = s0[i];
                 }
+                PROF_T(p5);
+                PROF_ADD(3, p4, p5);
             }
         }
 #pragma unroll
@@ -632,6 +514,77 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
             if (a.out.alpha_final) a.out.alpha_final[l] = alpha[t];
             if (a.out.v_final) for (int i = 0; i < NX; ++i) a.out.v_final[l * NX + i] = v[t][i];
             if (a.out.x_final) for (int i = 0; i < NX; ++i) a.out.x_final[l * NX + i] = x[t][i];
+        }
+    }
+#ifdef LBMPC_PROFILE
+    PROF_T(pk1);
+    prof[6] = pk1 - pk0;
+    if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&lbmpc_prof[i], (unsigned long long)prof[i]);
+#endif
+}
+#ifdef LBMPC_PROFILE
+extern "C" int lbmpc_prof_read(unsigned long long* out, int reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(lbmpc_prof), sizeof(z)) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(lbmpc_prof), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
+
+// All rejection draws of one closed-loop step for the T trials of a lane as ONE loop: each lane walks its own
+// queue of 2T tasks (xi_LV, xi_EV per trial; ModelingCar.m:42,36), one attempt per wave iteration, so the wave
+// runs max_lane(sum of attempts) iterations instead of sum_task(max_lane attempts).
+template <int NX, int T>
+__device__ __forceinline__ void sample_step(const SamplerDev* __restrict__ S, uint64_t seed, const uint64_t* tid,
+                                            uint32_t k, int max_attempts, double (*xi_lv)[NX], double (*xi_ev)[NX],
+                                            double (*Bul)[NX], int* status) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) sample_Bu_lv<NX>(S, seed, tid[t], k, P_ST_U, Bul[t]);
+    int cur = 0, att = 0;
+    while (__builtin_amdgcn_ballot_w64(cur < 2 * T) != 0) {
+        if (cur < 2 * T) {
+            uint64_t tidc = tid[0];
+#pragma unroll
+            for (int t = 1; t < T; ++t) tidc = ((cur >> 1) == t) ? tid[t] : tidc;
+            const bool ev = cur & 1;
+            double u[NX + (NX & 1)], xl[NX], xe[NX];
+            draw_uniforms<NX>(seed, tidc, k, ev ? P_ST_EV : P_ST_LV, (uint32_t)att, u);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                xl[i] = S->LV_lo[i] + (S->LV_hi[i] - S->LV_lo[i]) * u[i];
+                xe[i] = S->EV_lo[i] + (S->EV_hi[i] - S->EV_lo[i]) * u[i];
+            }
+            bool okl = true, oke = true;
+            for (int r = 0; r < S->nLV; ++r) {
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) acc = fma(S->LV_A[r * NX + i], xl[i], acc);
+                okl = okl && (acc <= S->LV_b[r]);
+            }
+            for (int r = 0; r < S->nEV; ++r) {
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) acc = fma(S->EV_A[r * NX + i], xe[i], acc);
+                oke = oke && (acc <= S->EV_b[r]);
+            }
+            const bool ok = ev ? oke : okl;
+            const bool last = att + 1 >= max_attempts;
+            if (ok || last) {
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const bool ml = cur == 2 * t, me = cur == 2 * t + 1;
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) {
+                        xi_lv[t][i] = ml ? xl[i] : xi_lv[t][i];
+                        xi_ev[t][i] = me ? xe[i] : xi_ev[t][i];
+                    }
+                    if (!ok && (ml || me)) status[t] = status[t] > LBMPC_ST_SAMPLER_CAP ? status[t] : LBMPC_ST_SAMPLER_CAP;
+                }
+                cur++;
+                att = 0;
+            } else {
+                att++;
+            }
         }
     }
 }
@@ -683,8 +636,8 @@ extern "C" int lbmpc_uqmpc_create(const lbmpc_params* p, lbmpc_ctx** out) {
     const int nx = p->nx, nu = p->nu, N = p->N, nc = p->nc, nz = nx + N * nu, nS = p->nS;
     if (nx < 1 || nu < 1 || N < 1 || nc < 1 || p->Nu < 0 || nS < 1) { set_error("lbmpc_uqmpc_create: bad size"); return LBMPC_ERR_ARG; }
     const int nH = nc * (p->Nu + 1);
-    if (nx > LBMPC_MAX_NX || nu > LBMPC_MAX_NU || nz > LBMPC_MAX_NZ || nc > LBMPC_MAX_NC || nS > 4096 || nH > 4096) {
-        set_error("lbmpc_uqmpc_create: limits nx<=%d nu<=%d nx+N*nu<=%d nc<=%d nS<=4096 nc*(Nu+1)<=4096", LBMPC_MAX_NX, LBMPC_MAX_NU, LBMPC_MAX_NZ, LBMPC_MAX_NC);
+    if (nx > LBMPC_MAX_NX || nu > LBMPC_MAX_NU || nz > LBMPC_MAX_NZ || nc > LBMPC_MAX_NC || nS > 2048 || nH > 2048) {
+        set_error("lbmpc_uqmpc_create: limits nx<=%d nu<=%d nx+N*nu<=%d nc<=%d nS<=2048 nc*(Nu+1)<=2048", LBMPC_MAX_NX, LBMPC_MAX_NU, LBMPC_MAX_NZ, LBMPC_MAX_NC);
         return LBMPC_ERR_DIM;
     }
     lbmpc_ctx* c = new lbmpc_ctx();
@@ -692,7 +645,8 @@ extern "C" int lbmpc_uqmpc_create(const lbmpc_params* p, lbmpc_ctx** out) {
     std::memset(&h, 0, sizeof(h));
     if (int rc = pack_box(p->W_A, p->W_b, p->nW, nx, &h.box)) { delete c; return rc; }
     h.nx = nx; h.nu = nu; h.N = N; h.nc = nc; h.Nu = p->Nu; h.nS = nS; h.nW = p->nW; h.nz = nz; h.nH = nH;
-    h.RL = (nx + 2) & ~1;  // [S_b, S_A row, pad] with an even pitch: rows are read as double2 broadcasts
+    h.RL = nx + 1;              // [S_b, S_A row]; chunks of 4 rows are read as double2 broadcasts
+    h.nSp = (nS + 7) & ~7;
     h.nzp = nz | 1;
     for (int i = 0; i < nx; ++i) for (int j = 0; j < nx; ++j) h.A[i * nx + j] = CMX(p->A, nx, i, j);
     for (int i = 0; i < nx; ++i) for (int j = 0; j < nu; ++j) h.B[i * nu + j] = CMX(p->B, nx, i, j);
@@ -724,8 +678,9 @@ extern "C" int lbmpc_uqmpc_create(const lbmpc_params* p, lbmpc_ctx** out) {
     for (int i = 0; i < ncv; ++i) for (int j = 0; j < ncv; ++j) P2[(nx + i) * nz + nx + j] = 2.0 * CMX(p->Pc, ncv, i, j);
     if (!invert_gj(nz, P2.data(), Ginv.data())) { set_error("lbmpc_uqmpc_create: cost matrix is singular"); delete c; return LBMPC_ERR_ARG; }
     for (int i = 0; i < nz; ++i) for (int j = i + 1; j < nz; ++j) { double s = 0.5 * (Ginv[i * nz + j] + Ginv[j * nz + i]); Ginv[i * nz + j] = Ginv[j * nz + i] = s; }
-    // S rows [S_b | S_A | pad]
-    std::vector<double> Srow((size_t)nS * h.RL, 0.0);
+    // S rows [S_b | S_A]; pad rows (b = 1e300, a = 0) can never be violated
+    std::vector<double> Srow((size_t)h.nSp * h.RL, 0.0);
+    for (int j = nS; j < h.nSp; ++j) Srow[(size_t)j * h.RL] = 1e300;
     for (int j = 0; j < nS; ++j) { Srow[(size_t)j * h.RL] = p->S_b[j]; for (int k = 0; k < nx; ++k) Srow[(size_t)j * h.RL + 1 + k] = CMX(p->S_A, nS, j, k); }
     // H rows: F_bar Psi^i, i = 0..Nu  (UQRobustMPC.m:153-155)
     std::vector<double> Hm((size_t)nH * h.nzp, 0.0), M((size_t)nc * nz), M2((size_t)nc * nz);
@@ -847,8 +802,9 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
     a.traj_trials = cfg->traj_trials; a.sampler_max_attempts = cfg->sampler_max_attempts;
     a.out = *out;
     // T = 2 trials per lane once there are enough trials to fill the chip at that width
-    // T = 2 trials per lane once 2-per-lane still fills every CU with a full block
+    hipStream_t st = (hipStream_t)stream;
     const char* env_t = getenv("LBMPC_MC_T");
+    // generic path: S rows broadcast from LDS; T = 2 trials per lane once 2-per-lane still fills every CU
     const bool wide = env_t ? (atoi(env_t) == 2) : (cfg->trials >= (int64_t)256 * 8 * 128);
     const int waves = pick_waves(c, 8);
     if (!waves) { set_error("constants (%zu B) do not fit in LDS", c->lds_const_bytes); return LBMPC_ERR_DIM; }
@@ -858,7 +814,6 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
     const int64_t resident = 256 * (int64_t)(LDS_LIMIT / lds > 4 ? 4 : (LDS_LIMIT / lds < 1 ? 1 : LDS_LIMIT / lds));
     if (blocks > resident * 4) blocks = resident * 4;
     dim3 grid((unsigned)blocks), blk(waves * 64);
-    hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_MC(NXV, TV)                                                                      \
     do {                                                                                        \
         if (int rc = allow_lds(mc_kernel<NXV, TV>, lds)) return rc;                             \

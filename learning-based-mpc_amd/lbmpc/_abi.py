@@ -101,7 +101,7 @@ def make_params(d):
 
 
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_DIR, "csrc", "liblbmpc_hip.so")
+LIB_PATH = os.environ.get("LBMPC_LIB") or os.path.join(_PKG_DIR, "csrc", "liblbmpc_hip.so")  # LBMPC_LIB: diagnostic builds only
 
 
 def declare(lib, prefix):

@@ -626,23 +626,25 @@ static int qp_solve(const orc_ctx* c, const double* q, double alpha, const doubl
                     for (int k = 0; k < nz; ++k) acc = fma(CA[a][k], g[k], acc);
                     rhs[a] = acc;
                 }
+                /* divisions by the diagonal are multiplications by its reciprocal (shared with the kernels) */
+                double invd[LBMPC_MAX_NZ];
                 for (int a = 0; a < nq; ++a)
                     for (int b = 0; b <= a; ++b) {
                         double acc = 0.0;
-                        for (int k = 0; k < nz; ++k) acc = fma(CA[a][k], Wm[b][k], acc);
+                        for (int k = 0; k < nz; ++k) acc = fma(CA[b][k], Wm[a][k], acc); /* M[a][b] = c_b . (Ginv c_a) */
                         for (int k = 0; k < b; ++k) acc = fma(-L[a][k], L[b][k], acc);
-                        if (a == b) L[a][a] = sqrt(acc > 0.0 ? acc : 0.0);
-                        else L[a][b] = acc / L[b][b];
+                        if (a == b) { L[a][a] = sqrt(acc > 0.0 ? acc : 0.0); invd[a] = 1.0 / L[a][a]; }
+                        else L[a][b] = acc * invd[b];
                     }
                 for (int a = 0; a < nq; ++a) { /* forward */
                     double acc = rhs[a];
                     for (int k = 0; k < a; ++k) acc = fma(-L[a][k], r[k], acc);
-                    r[a] = acc / L[a][a];
+                    r[a] = acc * invd[a];
                 }
                 for (int a = nq - 1; a >= 0; --a) { /* backward (terms applied in descending k: a column sweep) */
                     double acc = r[a];
                     for (int k = nq - 1; k > a; --k) acc = fma(-L[k][a], r[k], acc);
-                    r[a] = acc / L[a][a];
+                    r[a] = acc * invd[a];
                 }
                 for (int a = 0; a < nq; ++a) delta = fma(-rhs[a], r[a], delta);
             }

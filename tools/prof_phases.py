@@ -1,0 +1,29 @@
+"""In-kernel phase timing of mc_kernel (build with -DLBMPC_PROFILE; see tools/prof.sh).  Diagnostic only."""
+import ctypes, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "learning-based-mpc_amd"))
+from lbmpc import core, params, _abi
+
+P = params.load("4x4")
+ctx = core.Context(P)
+smp = params.sampler(P)
+trials = int(os.environ.get("TRIALS", 131072)); K = int(os.environ.get("K", 1000))
+lib = _abi.load()
+buf = (ctypes.c_ulonglong * 16)()
+lib.lbmpc_prof_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
+for rep in range(2):
+    lib.lbmpc_prof_read(buf, 1)
+    t0 = time.time()
+    out = ctx.mc_run(smp, trials=trials, steps=K, card_I0=10, x0=[-12, 5, 0, 0], seed=4,
+                     acc_bound=float(P["acc_bound"][0]), distance_error=float(P["distance_error"][0]))
+    dt = time.time() - t0
+    lib.lbmpc_prof_read(buf, 0)
+v = np.array(list(buf), dtype=np.float64)
+tot = v[6]
+names = ["sample_lv+uq+tighten", "first_pass", "solve", "ev+dynamics"]
+print(f"wall {dt*1e3:.1f} ms (incl. copies); waves*cycles total {tot:.3e}")
+for i, n in enumerate(names):
+    print(f"  {n:24s} {v[i]/tot*100:6.2f} %")
+print(f"  flagged solves {v[4]:.0f}  group rounds {v[5]:.0f}  mean iters/trial {np.mean(out['qp_iters']):.2f}")
+if v[5] > 0:
+    print(f"  cycles per group round {v[2]/v[5]:.0f}")
