@@ -85,6 +85,145 @@ __device__ __forceinline__ void load_row(const CtxDev* __restrict__ C, const Lds
     }
 }
 
+// Set / clear the scan bit of row p of QP g (p, flag: row-uniform in row g) in the lane that scans that row.
+__device__ __forceinline__ void mark_rows(bool flag, int p, int nS, int lane, uint32_t* actS, uint32_t* actH, bool set) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (__builtin_amdgcn_readlane((int)flag, 16 * g)) {  // wave-uniform branch
+            const int pg = __builtin_amdgcn_readlane(p, 16 * g);
+            const bool srow = pg < nS;
+            const int hh = srow ? pg : pg - nS;
+            const uint32_t bit = ((hh & 63) == lane) ? (1u << (hh >> 6)) : 0u;
+            if (set) { actS[g] |= srow ? bit : 0u; actH[g] |= srow ? 0u : bit; }
+            else { actS[g] &= ~(srow ? bit : 0u); actH[g] &= ~(srow ? 0u : bit); }
+        }
+    }
+}
+
+// Pivot scan for the four QPs of the wave at once.  Lane l evaluates rows l, l+64, ... for ALL four QPs: every row
+// is fetched from LDS once per wave (64 distinct rows per ds_read, next rows in flight during the arithmetic), the
+// per-QP operands (alpha_g, e_g = q_g + s0_g, z_g) are wave-uniform.  Returns this ROW's (best, bj).
+// slack_S[j] = alpha S_b[j] + S_A[j,:] e ; slack_H[h] = (1-h_k)[h % nc] - H[h,:] z ; strict <, ties -> lowest index.
+template <int NX>
+__device__ __forceinline__ void scan_rows(const CtxDev* __restrict__ C, const LdsView& L, const double* wws,
+                                          double alpha, const double* q, double my_z, const uint32_t* actS,
+                                          const uint32_t* actH, double& best_out, int& bj_out) {
+    constexpr int RLc = NX + 1;
+    const int lane = lane_id(), grp = lane >> 4;
+    const int nS = C->nS, nH = C->nH, nc = C->nc, nzp = C->nzp, nz = C->nz;
+    double ea[4], ee[4][NX], best[4];
+    int bj[4];
+    {
+        double e[NX];
+        static_for<0, NX>([&](auto K) { constexpr int k = K; e[k] = q[k] + rowb<k>(my_z); });
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            ea[g] = readlane_f64(alpha, 16 * g);
+#pragma unroll
+            for (int k = 0; k < NX; ++k) ee[g][k] = readlane_f64(e[k], 16 * g);
+            best[g] = -QP_TOL_VIOL; bj[g] = 0x7fffffff;
+        }
+    }
+    // ---- S rows (padded to a multiple of 128 with never-violated rows) ----
+    {
+        const int nch = C->nSp >> 6;  // even
+        const double* base = L.Srow + lane * RLc;
+        double A[RLc], B[RLc];
+        auto eval = [&](const double* cf, int m) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                double acc = ea[g] * cf[0];
+#pragma unroll
+                for (int k = 0; k < NX; ++k) acc = fma(cf[1 + k], ee[g][k], acc);
+                const bool ok = !((actS[g] >> m) & 1u) && acc < best[g];
+                best[g] = ok ? acc : best[g];
+                bj[g] = ok ? lane + 64 * m : bj[g];
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < RLc; ++k) A[k] = base[k];
+        for (int m = 0; m < nch; m += 2) {
+            const double* pb = base + (m + 1) * 64 * RLc;
+#pragma unroll
+            for (int k = 0; k < RLc; ++k) B[k] = pb[k];
+            __builtin_amdgcn_sched_barrier(0);
+            eval(A, m);
+            const double* pa = base + (m + 2 < nch ? m + 2 : 0) * 64 * RLc;
+#pragma unroll
+            for (int k = 0; k < RLc; ++k) A[k] = pa[k];
+            __builtin_amdgcn_sched_barrier(0);
+            eval(B, m + 1);
+        }
+    }
+    // ---- H rows (storage padded to a multiple of 128 rows; rows >= nH are skipped), two QPs per pass ----
+    {
+        const int nchH = C->nHp >> 6;
+        const int nz4 = (nz + 3) >> 2;
+#pragma unroll
+        for (int g0 = 0; g0 < 4; g0 += 2) {
+            double zu[2][NZMAX];
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+                for (int k = 0; k < NZMAX; ++k) zu[gg][k] = (k < 4 * nz4) ? readlane_f64(my_z, 16 * (g0 + gg) + k) : 0.0;
+            int r = lane % nc;
+            const int rstep = 64 % nc;
+            const double* hb = L.Hm + lane * nzp;
+            double rowA[NZMAX], rowB[NZMAX];
+            auto fetch = [&](double* dst, int m) {
+                const double* hp = hb + m * 64 * nzp;
+#pragma unroll
+                for (int k4 = 0; k4 < NZMAX / 4; ++k4)
+                    if (k4 < nz4) {
+#pragma unroll
+                        for (int k = 4 * k4; k < 4 * k4 + 4; ++k) dst[k] = hp[k];
+                    }
+            };
+            auto eval = [&](const double* row, int m, double o0, double o1) {
+                const int h = lane + 64 * m;
+                double acc0 = o0, acc1 = o1;
+#pragma unroll
+                for (int k4 = 0; k4 < NZMAX / 4; ++k4)
+                    if (k4 < nz4) {
+#pragma unroll
+                        for (int k = 4 * k4; k < 4 * k4 + 4; ++k) {
+                            acc0 = fma(-row[k], zu[0][k], acc0);
+                            acc1 = fma(-row[k], zu[1][k], acc1);
+                        }
+                    }
+                const bool in = h < nH;
+                const bool ok0 = in && !((actH[g0] >> m) & 1u) && acc0 < best[g0];
+                const bool ok1 = in && !((actH[g0 + 1] >> m) & 1u) && acc1 < best[g0 + 1];
+                best[g0] = ok0 ? acc0 : best[g0];         bj[g0] = ok0 ? nS + h : bj[g0];
+                best[g0 + 1] = ok1 ? acc1 : best[g0 + 1]; bj[g0 + 1] = ok1 ? nS + h : bj[g0 + 1];
+            };
+            auto omh = [&](int gg, int& rr) {  // (1 - h_k)[h % nc] of QP g0+gg for the row of this m-step
+                return wws[(g0 + gg) * GWS_DOUBLES + rr];
+            };
+            fetch(rowA, 0);
+            for (int m = 0; m < nchH; m += 2) {  // nchH is even
+                fetch(rowB, m + 1);
+                const double a0 = omh(0, r), a1 = omh(1, r);
+                r += rstep; r = r >= nc ? r - nc : r;
+                const double b0 = omh(0, r), b1 = omh(1, r);
+                r += rstep; r = r >= nc ? r - nc : r;
+                __builtin_amdgcn_sched_barrier(0);
+                eval(rowA, m, a0, a1);
+                fetch(rowA, m + 2 < nchH ? m + 2 : 0);
+                __builtin_amdgcn_sched_barrier(0);
+                eval(rowB, m + 1, b0, b1);
+            }
+        }
+    }
+    best_out = 0.0; bj_out = 0x7fffffff;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        wave_argmin(best[g], bj[g]);
+        best_out = grp == g ? best[g] : best_out;
+        bj_out = grp == g ? bj[g] : bj_out;
+    }
+}
+
 // Append row `a` (row-uniform) to the factor: lane b <= a forms M[a][b] = c_b . g_a (c_b = its own active row, g_a
 // broadcast from the lanes holding it), the row solve is a column sweep, lane a gets the diagonal.
 template <int NX>
@@ -129,14 +268,23 @@ __device__ __forceinline__ void chol_append_row(const CtxDev* __restrict__ C, co
 // gws: this ROW's LDS slot (omh filled by the caller; results written at the end).
 template <int NX>
 __device__ __forceinline__ void group_qp_solve(const CtxDev* __restrict__ C, const LdsView& L, double* gws, bool live,
-                                               double alpha, const double* q) {
-    const int i = lane_id() & 15;
-    const int nz = C->nz, nS = C->nS, nH = C->nH, nc = C->nc, RL = C->RL, nzp = C->nzp;
-    const int mS = (nS + 15) >> 4, mH = (nH + 15) >> 4;
+                                               double alpha, const double* q, long long* prof = nullptr) {
+#ifdef LBMPC_PROFILE
+#define GP_T(var) const long long var = clock64()
+#define GP_ADD(slot, t0, t1) prof[slot] += (t1) - (t0)
+#define GP_INC(slot) prof[slot] += 1
+#else
+#define GP_T(var)
+#define GP_ADD(slot, t0, t1)
+#define GP_INC(slot)
+#endif
+    const int lane = lane_id(), i = lane & 15, grp = lane >> 4;
+    const int nz = C->nz, nS = C->nS;
     bool done = !live, have_p = false;
     int nq = 0, iters = 0, status = 0, p = 0;
     double sp = 0.0, cg = 0.0;
-    uint64_t actS0 = 0, actS1 = 0, actH0 = 0, actH1 = 0;  // bit m: my m-th S / H row (i + 16 m) is active
+    // scan bookkeeping is per LANE (not per row): bit m of actS[g] / actH[g] = row lane + 64 m is active in QP g
+    uint32_t actS[4] = {0, 0, 0, 0}, actH[4] = {0, 0, 0, 0};
     double my_u = 0.0, my_z = 0.0, my_g = 0.0, my_invd = 1.0;
     int my_act = 0;
     double LL[NZMAX], WmK[NZMAX];
@@ -146,39 +294,13 @@ __device__ __forceinline__ void group_qp_solve(const CtxDev* __restrict__ C, con
     while (__builtin_amdgcn_ballot_w64(!done) != 0) {
         // ---- Step 1: most violated row at the current z (rows without a pivot) ----
         const bool need_scan = !done && !have_p;
+        GP_T(g0);
+        GP_INC(4);
         if (__builtin_amdgcn_ballot_w64(need_scan) != 0) {
-            double zr[NZMAX], e[NX];
-            static_for<0, NZMAX>([&](auto K) { constexpr int k = K; zr[k] = rowb<k>(my_z); });
-#pragma unroll
-            for (int k = 0; k < NX; ++k) e[k] = q[k] + zr[k];
+            GP_INC(5);
             double best = -QP_TOL_VIOL;
             int bj = 0x7fffffff;
-#pragma unroll 4
-            for (int m = 0; m < mS; ++m) {
-                const int j = i + 16 * m;
-                const double* row = L.Srow + (j < nS ? j : 0) * RL;
-                double acc = alpha * row[0];
-#pragma unroll
-                for (int k = 0; k < NX; ++k) acc = fma(row[1 + k], e[k], acc);
-                const uint64_t mk = m < 64 ? actS0 : actS1;
-                if (j < nS && !((mk >> (m & 63)) & 1) && acc < best) { best = acc; bj = j; }
-            }
-            int r = i % nc;
-            const int rstep = 16 % nc;
-#pragma unroll 2
-            for (int m = 0; m < mH; ++m) {
-                const int h = i + 16 * m;
-                const double* row = L.Hm + (h < nH ? h : 0) * nzp;
-                double acc = gws[r];
-#pragma unroll
-                for (int k = 0; k < NZMAX; ++k)
-                    if (k < nz) acc = fma(-row[k], zr[k], acc);
-                const uint64_t mk = m < 64 ? actH0 : actH1;
-                if (h < nH && !((mk >> (m & 63)) & 1) && acc < best) { best = acc; bj = nS + h; }
-                r += rstep;
-                if (r >= nc) r -= nc;
-            }
-            row_argmin(best, bj);
+            scan_rows<NX>(C, L, gws - grp * GWS_DOUBLES, alpha, q, my_z, actS, actH, best, bj);
             const bool optimal = need_scan && bj == 0x7fffffff;
             const bool newp = need_scan && !optimal;
             done = done || optimal;
@@ -205,6 +327,8 @@ __device__ __forceinline__ void group_qp_solve(const CtxDev* __restrict__ C, con
             }
         }
         // ---- Step 2 for every row that is not done ----
+        GP_T(g1);
+        GP_ADD(0, g0, g1);
         const bool act2 = !done;
         if (act2) {
             iters += 1;
@@ -271,36 +395,27 @@ __device__ __forceinline__ void group_qp_solve(const CtxDev* __restrict__ C, con
         }
         const bool full = upd && !dependent && t2 <= t1;
         const bool drop = upd && !full;
+        GP_T(g2);
+        GP_ADD(1, g1, g2);
         if (__builtin_amdgcn_ballot_w64(full) != 0) {
             // full step: constraint p joins the active set as number nq
             if (full && i == nq) my_act = p;
 #pragma unroll
             for (int a = 0; a < NZMAX; ++a) WmK[a] = (full && a == nq) ? my_g : WmK[a];
             chol_append_row<NX>(C, L, full, nq, my_act, my_g, i, LL, my_invd);
+            mark_rows(full, p, nS, lane, actS, actH, true);
             if (full) {
-                const int hh = p < nS ? p : p - nS;
-                const int m = hh >> 4;
-                if ((hh & 15) == i) {
-                    const uint64_t bit = 1ull << (m & 63);
-                    if (p < nS) { if (m < 64) actS0 |= bit; else actS1 |= bit; }
-                    else { if (m < 64) actH0 |= bit; else actH1 |= bit; }
-                }
                 nq += 1;
                 have_p = false;
             }
         }
+        GP_T(g3);
+        GP_ADD(2, g2, g3);
         if (__builtin_amdgcn_ballot_w64(drop) != 0) {
+            GP_INC(6);
             // partial / dual-only step: drop active constraint kdrop, stay in step 2 with the same pivot
             const int pd = row_max_i32((drop && i == kdrop) ? my_act : -1);
-            if (drop) {
-                const int hh = pd < nS ? pd : pd - nS;
-                const int m = hh >> 4;
-                if ((hh & 15) == i) {
-                    const uint64_t bit = ~(1ull << (m & 63));
-                    if (pd < nS) { if (m < 64) actS0 &= bit; else actS1 &= bit; }
-                    else { if (m < 64) actH0 &= bit; else actH1 &= bit; }
-                }
-            }
+            mark_rows(drop, pd, nS, lane, actS, actH, false);
             const int nxt_act = dpp_i32<0x101>(my_act);   // row_shl:1 : lane i receives lane i+1
             const double nxt_u = dpp_f64<0x101>(my_u);
             if (drop && i >= kdrop && i < nq) { my_act = nxt_act; my_u = nxt_u; }
@@ -327,6 +442,8 @@ __device__ __forceinline__ void group_qp_solve(const CtxDev* __restrict__ C, con
                 }
             });
         }
+        GP_T(g4);
+        GP_ADD(3, g3, g4);
     }
     // results -> this row's LDS slot
     gws[16 + i] = my_z;

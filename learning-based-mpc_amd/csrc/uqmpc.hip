@@ -32,7 +32,7 @@ namespace lbmpc {
 #define NZMAX LBMPC_MAX_NZ
 
 struct CtxDev {
-    int nx, nu, N, nc, Nu, nS, nW, nz, nH, RL, nzp, nSp;  // nSp: S rows padded to a multiple of 8 (never-active pad rows)
+    int nx, nu, N, nc, Nu, nS, nW, nz, nH, RL, nzp, nSp, nHp;  // nSp, nHp: S / H row storage padded to a multiple of 128
     double A[LBMPC_MAX_NX * LBMPC_MAX_NX];    // row-major
     double B[LBMPC_MAX_NX * LBMPC_MAX_NU];    // row-major nx x nu
     double K[LBMPC_MAX_NU * LBMPC_MAX_NX];    // row-major nu x nx
@@ -53,6 +53,11 @@ struct lbmpc_ctx {
     double *dS = nullptr, *dH = nullptr, *dG = nullptr;
     int device = 0;
     size_t lds_const_bytes = 0;
+    // grow-only scratch of lbmpc_mc_run: pre-drawn step disturbances of one trial chunk (+ their cap flags)
+    double* xi = nullptr;
+    size_t xi_bytes = 0;
+    int* xi_status = nullptr;
+    size_t xi_status_n = 0;
 };
 
 namespace lbmpc {
@@ -192,7 +197,7 @@ __device__ __forceinline__ void first_pass(const CtxDev* __restrict__ C, const L
 }
 
 __device__ __forceinline__ void stage_constants(const CtxDev* __restrict__ C, double* lds) {
-    const int nS_RL = C->nSp * C->RL, nH_nzp = C->nH * C->nzp, nzz = C->nz * C->nz;
+    const int nS_RL = C->nSp * C->RL, nH_nzp = C->nHp * C->nzp, nzz = C->nz * C->nz;
     for (int i = threadIdx.x; i < nS_RL; i += blockDim.x) lds[i] = C->Srow[i];
     for (int i = threadIdx.x; i < nH_nzp; i += blockDim.x) lds[nS_RL + i] = C->Hm[i];
     for (int i = threadIdx.x; i < nzz; i += blockDim.x) lds[nS_RL + nH_nzp + i] = C->Ginv[i];
@@ -206,7 +211,7 @@ __device__ __forceinline__ void solve_flagged(const CtxDev* __restrict__ C, cons
                                               bool need, double alpha, const double* v, const double* q,
                                               double* s0, double* c0, int& status, int& iters,
                                               int* nact_out, int* act_out /* NZMAX, sorted, or null */,
-                                              double* c_full /* nz-NX or null */) {
+                                              double* c_full /* nz-NX or null */, long long* prof = nullptr) {
     const int lane = lane_id(), grp = lane >> 4;
     uint64_t mask = __builtin_amdgcn_ballot_w64(need);
     while (mask) {
@@ -234,7 +239,7 @@ __device__ __forceinline__ void solve_flagged(const CtxDev* __restrict__ C, cons
         if (mygrp >= 0)
             for (int r = 0; r < C->nc; ++r) wws[mygrp * GWS_DOUBLES + r] = 1.0 - hk_value<NX>(C, alpha, v, r);
         wave_sync();
-        group_qp_solve<NX>(C, L, wws + grp * GWS_DOUBLES, live, a_g, q_g);
+        group_qp_solve<NX>(C, L, wws + grp * GWS_DOUBLES, live, a_g, q_g, prof);
         wave_sync();
         if (mygrp >= 0) {
             const double* gw = wws + mygrp * GWS_DOUBLES;
@@ -274,10 +279,10 @@ __global__ __launch_bounds__(256) void uqmpc_step_kernel(const CtxDev* __restric
     extern __shared__ double lds[];
     stage_constants(C, lds);
     LdsView L;
-    L.Srow = lds; L.Hm = lds + C->nSp * C->RL; L.Ginv = L.Hm + C->nH * C->nzp;
+    L.Srow = lds; L.Hm = lds + C->nSp * C->RL; L.Ginv = L.Hm + C->nHp * C->nzp;
     const int wave = threadIdx.x / LB_WAVE, nwaves = blockDim.x / LB_WAVE, lane = lane_id();
     const int nz = C->nz, ncv = nz - NX;
-    double* ws = lds + C->nSp * C->RL + C->nH * C->nzp + nz * nz + wave * ws_doubles(nz);
+    double* ws = lds + C->nSp * C->RL + C->nHp * C->nzp + nz * nz + wave * ws_doubles(nz);
     for (int64_t base = ((int64_t)blockIdx.x * nwaves + wave) * LB_WAVE; base < batch;
          base += (int64_t)gridDim.x * nwaves * LB_WAVE) {
         const int64_t b = base + lane;
@@ -353,14 +358,69 @@ struct McArgs {
     double x0[LBMPC_MAX_NX];
     double acc_bound, distance_error;
     int traj_trials, sampler_max_attempts;
+    // this launch covers local trials [chunk0, chunk0 + chunk_n); xi holds their pre-drawn step disturbances
+    int64_t chunk0, chunk_n;
+    const double* xi;       // [step][chunk trial][LV nx | EV nx]
+    const int* xi_status;   // [chunk trial] LBMPC_ST_SAMPLER_CAP if a step sampler hit the attempt cap
     lbmpc_mc_out out;
 };
+
+// ---- step-disturbance pre-pass ------------------------------------------------------------------------
+// xi_LV / xi_EV of every (trial, step) by rejection sampling (ModelingCar.m:36-43 via :47-91).  The draws depend on
+// (seed, trial, step, attempt) only, not on the closed-loop state, so they are produced ahead of the closed loop:
+// here every lane walks its own (step, attempt) sequence and no lane waits for another lane's rejections (inside
+// the lock-step closed loop a wave pays the maximum attempt count of its 64 lanes at every step).
+// grid.y = 0: xi_LV, 1: xi_EV.  Same streams and arithmetic as sample_polytope.
+template <int NX>
+__global__ __launch_bounds__(256) void mc_sample_kernel(SamplerDev smp, int64_t chunk_n, int64_t trial_first, int K,
+                                                        uint64_t seed, int max_attempts, double* __restrict__ xi,
+                                                        int* __restrict__ xi_status) {
+    const int kind = blockIdx.y;
+    const int64_t cl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = cl < chunk_n;
+    const uint64_t tid = (uint64_t)(trial_first + (valid ? cl : chunk_n - 1));
+    const double* XA = kind ? smp.EV_A : smp.LV_A;
+    const double* Xb = kind ? smp.EV_b : smp.LV_b;
+    const double* lo = kind ? smp.EV_lo : smp.LV_lo;
+    const double* hi = kind ? smp.EV_hi : smp.LV_hi;
+    const int nr = kind ? smp.nEV : smp.nLV;
+    const uint32_t purpose = kind ? P_ST_EV : P_ST_LV;
+    int k = valid ? 0 : K, att = 0, st = 0;
+    while (__builtin_amdgcn_ballot_w64(k < K) != 0) {
+        if (k < K) {
+            double u[NX + (NX & 1)], xt[NX];
+            draw_uniforms<NX>(seed, tid, (uint32_t)k, purpose, (uint32_t)att, u);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xt[i] = lo[i] + (hi[i] - lo[i]) * u[i];
+            bool ok = true;
+            for (int r = 0; r < nr; ++r) {
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) acc = fma(XA[r * NX + i], xt[i], acc);
+                ok = ok && (acc <= Xb[r]);
+            }
+            const bool last = att + 1 >= max_attempts;
+            if (ok || last) {
+                double* dst = xi + (((int64_t)k * chunk_n + cl) * 2 + kind) * NX;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) dst[i] = xt[i];
+                if (!ok) st = LBMPC_ST_SAMPLER_CAP;
+                ++k; att = 0;
+            } else {
+                ++att;
+            }
+        }
+    }
+    if (valid && st) atomicMax(&xi_status[cl], st);
+}
 
 #ifdef LBMPC_PROFILE
 __device__ unsigned long long lbmpc_prof[16];
 #define PROF_T(var) const long long var = clock64()
 #define PROF_ADD(slot, t0, t1) prof[slot] += (t1) - (t0)
+#define PROF_PTR (prof + 8)
 #else
+#define PROF_PTR nullptr
 #define PROF_T(var)
 #define PROF_ADD(slot, t0, t1)
 #endif
@@ -370,18 +430,18 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
     extern __shared__ double lds[];
     stage_constants(C, lds);
     LdsView L;
-    L.Srow = lds; L.Hm = lds + C->nSp * C->RL; L.Ginv = L.Hm + C->nH * C->nzp;
+    L.Srow = lds; L.Hm = lds + C->nSp * C->RL; L.Ginv = L.Hm + C->nHp * C->nzp;
     const int wave = threadIdx.x / LB_WAVE, nwaves = blockDim.x / LB_WAVE, lane = lane_id();
     const int nz = C->nz, nu = C->nu, K = a.steps;
-    double* ws = lds + C->nSp * C->RL + C->nH * C->nzp + nz * nz + wave * ws_doubles(nz);
+    double* ws = lds + C->nSp * C->RL + C->nHp * C->nzp + nz * nz + wave * ws_doubles(nz);
     const SamplerDev* S = &smp;
 #ifdef LBMPC_PROFILE
-    long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     PROF_T(pk0);
 #endif
-    for (int64_t base = ((int64_t)blockIdx.x * nwaves + wave) * (LB_WAVE * T); base < a.trials;
+    for (int64_t base = ((int64_t)blockIdx.x * nwaves + wave) * (LB_WAVE * T); base < a.chunk_n;
          base += (int64_t)gridDim.x * nwaves * (LB_WAVE * T)) {
-        int64_t tl[T];      // local trial index
+        int64_t tl[T], cl[T];  // local trial index (output arrays), index inside this chunk (xi)
         uint64_t tid[T];    // global id = RNG stream key
         bool valid[T];
         double x[T][NX], wst[T][NX], v[T][NX], alpha[T];
@@ -389,10 +449,11 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int64_t l = base + t * LB_WAVE + lane;
-            valid[t] = l < a.trials;
-            tl[t] = valid[t] ? l : a.trials - 1;
+            valid[t] = l < a.chunk_n;
+            cl[t] = valid[t] ? l : a.chunk_n - 1;
+            tl[t] = a.chunk0 + cl[t];
             tid[t] = (uint64_t)(a.trial0 + tl[t]);
-            status[t] = 0; infeasible[t] = 0; iters[t] = 0;
+            status[t] = a.steps > 0 ? a.xi_status[cl[t]] : 0; infeasible[t] = 0; iters[t] = 0;
             // initial set learning: InitialSetComputation.solve (:48-59), card_I0 samples
             double m[2 * NX];
 #pragma unroll
@@ -423,15 +484,18 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
             }
         }
         for (int k = 0; k < K; ++k) {
-            double q[T][NX], xi_lv[T][NX], Bul[T][NX], momh[T];
+            double q[T][NX], xi_lv[T][NX], xi_ev[T][NX], Bul[T][NX], momh[T];
             int aomh[T];
             bool need[T];
             PROF_T(p0);
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                // LVModeling first (Case_3...:58; ModelingCar.m:42-43)
-                if (sample_polytope<NX>(S->LV_A, S->LV_b, S->nLV, S->LV_lo, S->LV_hi, a.seed, tid[t], (uint32_t)k, P_ST_LV, a.sampler_max_attempts, xi_lv[t]))
-                    status[t] = status[t] > LBMPC_ST_SAMPLER_CAP ? status[t] : LBMPC_ST_SAMPLER_CAP;
+                // LVModeling first (Case_3...:58; ModelingCar.m:42-43): xi_LV, xi_EV come from the pre-pass
+                {
+                    const double* xp = a.xi + (((int64_t)k * a.chunk_n + cl[t]) * 2) * NX;
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) { xi_lv[t][i] = xp[i]; xi_ev[t][i] = xp[NX + i]; }
+                }
                 sample_Bu_lv<NX>(S, a.seed, tid[t], (uint32_t)k, P_ST_U, Bul[t]);
                 double bh[2 * NX];
                 int st = uq_update<NX>(C, alpha[t], v[t], wst[t], bh);  // w_new = 0 at k = 0 (Case_3...:62-65)
@@ -455,11 +519,11 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
                 prof[5] += (__builtin_popcountll(__builtin_amdgcn_ballot_w64(valid[t] && need[t])) + 3) >> 2;
 #endif
                 solve_flagged<NX>(C, L, ws, valid[t] && need[t], alpha[t], v[t], q[t], s0, c0,
-                                  status[t], iters[t], nullptr, nullptr, nullptr);
+                                  status[t], iters[t], nullptr, nullptr, nullptr, PROF_PTR);
                 PROF_T(p4);
                 PROF_ADD(2, p3, p4);
                 // u = K x + c(1:nu); EVModeling (ModelingCar.m:36-37); relative dynamics
-                double xi_ev[NX], Ax[NX], Bu[NX], xn[NX];
+                double Ax[NX], Bu[NX], xn[NX];
 #pragma unroll
                 for (int j = 0; j < LBMPC_MAX_NU; ++j) {
                     u[j] = 0.0;
@@ -471,8 +535,6 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
                         if (acc > a.acc_bound || acc < -a.acc_bound) infeasible[t] = 1;
                     }
                 }
-                if (sample_polytope<NX>(S->EV_A, S->EV_b, S->nEV, S->EV_lo, S->EV_hi, a.seed, tid[t], (uint32_t)k, P_ST_EV, a.sampler_max_attempts, xi_ev))
-                    status[t] = status[t] > LBMPC_ST_SAMPLER_CAP ? status[t] : LBMPC_ST_SAMPLER_CAP;
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
                     double acc = 0.0, bcc = 0.0;
@@ -481,7 +543,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
 #pragma unroll
                     for (int j = 0; j < LBMPC_MAX_NU; ++j) if (j < nu) bcc = fma(C->B[i * nu + j], u[j], bcc);
                     Ax[i] = acc; Bu[i] = bcc;
-                    xn[i] = ((Ax[i] + Bu[i]) + xi_ev[i]) - (xi_lv[t][i] + Bul[t][i]);
+                    xn[i] = ((Ax[i] + Bu[i]) + xi_ev[t][i]) - (xi_lv[t][i] + Bul[t][i]);
                 }
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
@@ -519,7 +581,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
 #ifdef LBMPC_PROFILE
     PROF_T(pk1);
     prof[6] = pk1 - pk0;
-    if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&lbmpc_prof[i], (unsigned long long)prof[i]);
+    if (lane == 0) for (int i = 0; i < 16; ++i) atomicAdd(&lbmpc_prof[i], (unsigned long long)prof[i]);
 #endif
 }
 #ifdef LBMPC_PROFILE
@@ -530,64 +592,6 @@ extern "C" int lbmpc_prof_read(unsigned long long* out, int reset) {
     return 0;
 }
 #endif
-
-// All rejection draws of one closed-loop step for the T trials of a lane as ONE loop: each lane walks its own
-// queue of 2T tasks (xi_LV, xi_EV per trial; ModelingCar.m:42,36), one attempt per wave iteration, so the wave
-// runs max_lane(sum of attempts) iterations instead of sum_task(max_lane attempts).
-template <int NX, int T>
-__device__ __forceinline__ void sample_step(const SamplerDev* __restrict__ S, uint64_t seed, const uint64_t* tid,
-                                            uint32_t k, int max_attempts, double (*xi_lv)[NX], double (*xi_ev)[NX],
-                                            double (*Bul)[NX], int* status) {
-#pragma unroll
-    for (int t = 0; t < T; ++t) sample_Bu_lv<NX>(S, seed, tid[t], k, P_ST_U, Bul[t]);
-    int cur = 0, att = 0;
-    while (__builtin_amdgcn_ballot_w64(cur < 2 * T) != 0) {
-        if (cur < 2 * T) {
-            uint64_t tidc = tid[0];
-#pragma unroll
-            for (int t = 1; t < T; ++t) tidc = ((cur >> 1) == t) ? tid[t] : tidc;
-            const bool ev = cur & 1;
-            double u[NX + (NX & 1)], xl[NX], xe[NX];
-            draw_uniforms<NX>(seed, tidc, k, ev ? P_ST_EV : P_ST_LV, (uint32_t)att, u);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                xl[i] = S->LV_lo[i] + (S->LV_hi[i] - S->LV_lo[i]) * u[i];
-                xe[i] = S->EV_lo[i] + (S->EV_hi[i] - S->EV_lo[i]) * u[i];
-            }
-            bool okl = true, oke = true;
-            for (int r = 0; r < S->nLV; ++r) {
-                double acc = 0.0;
-#pragma unroll
-                for (int i = 0; i < NX; ++i) acc = fma(S->LV_A[r * NX + i], xl[i], acc);
-                okl = okl && (acc <= S->LV_b[r]);
-            }
-            for (int r = 0; r < S->nEV; ++r) {
-                double acc = 0.0;
-#pragma unroll
-                for (int i = 0; i < NX; ++i) acc = fma(S->EV_A[r * NX + i], xe[i], acc);
-                oke = oke && (acc <= S->EV_b[r]);
-            }
-            const bool ok = ev ? oke : okl;
-            const bool last = att + 1 >= max_attempts;
-            if (ok || last) {
-#pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    const bool ml = cur == 2 * t, me = cur == 2 * t + 1;
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) {
-                        xi_lv[t][i] = ml ? xl[i] : xi_lv[t][i];
-                        xi_ev[t][i] = me ? xe[i] : xi_ev[t][i];
-                    }
-                    if (!ok && (ml || me)) status[t] = status[t] > LBMPC_ST_SAMPLER_CAP ? status[t] : LBMPC_ST_SAMPLER_CAP;
-                }
-                cur++;
-                att = 0;
-            } else {
-                att++;
-            }
-        }
-    }
-}
 
 // ---- host: context ----------------------------------------------------------------------------------
 static bool invert_gj(int n, const double* M /* row-major */, double* Minv) {
@@ -624,6 +628,8 @@ extern "C" void lbmpc_destroy(lbmpc_ctx* c) {
     if (c->dS) (void)hipFree(c->dS);
     if (c->dH) (void)hipFree(c->dH);
     if (c->dG) (void)hipFree(c->dG);
+    if (c->xi) (void)hipFree(c->xi);
+    if (c->xi_status) (void)hipFree(c->xi_status);
     delete c;
 }
 
@@ -646,8 +652,9 @@ extern "C" int lbmpc_uqmpc_create(const lbmpc_params* p, lbmpc_ctx** out) {
     if (int rc = pack_box(p->W_A, p->W_b, p->nW, nx, &h.box)) { delete c; return rc; }
     h.nx = nx; h.nu = nu; h.N = N; h.nc = nc; h.Nu = p->Nu; h.nS = nS; h.nW = p->nW; h.nz = nz; h.nH = nH;
     h.RL = nx + 1;              // [S_b, S_A row]; chunks of 4 rows are read as double2 broadcasts
-    h.nSp = (nS + 7) & ~7;
-    h.nzp = nz | 1;
+    h.nSp = (nS + 127) & ~127;  // pad rows can never be violated
+    h.nHp = (nH + 127) & ~127;  // zero rows, skipped by index
+    h.nzp = ((nz + 3) & ~3) | 1;  // odd pitch: conflict-free per-lane row reads
     for (int i = 0; i < nx; ++i) for (int j = 0; j < nx; ++j) h.A[i * nx + j] = CMX(p->A, nx, i, j);
     for (int i = 0; i < nx; ++i) for (int j = 0; j < nu; ++j) h.B[i * nu + j] = CMX(p->B, nx, i, j);
     for (int j = 0; j < nu; ++j) for (int k = 0; k < nx; ++k) h.K[j * nx + k] = CMX(p->K, nu, j, k);
@@ -683,7 +690,7 @@ extern "C" int lbmpc_uqmpc_create(const lbmpc_params* p, lbmpc_ctx** out) {
     for (int j = nS; j < h.nSp; ++j) Srow[(size_t)j * h.RL] = 1e300;
     for (int j = 0; j < nS; ++j) { Srow[(size_t)j * h.RL] = p->S_b[j]; for (int k = 0; k < nx; ++k) Srow[(size_t)j * h.RL + 1 + k] = CMX(p->S_A, nS, j, k); }
     // H rows: F_bar Psi^i, i = 0..Nu  (UQRobustMPC.m:153-155)
-    std::vector<double> Hm((size_t)nH * h.nzp, 0.0), M((size_t)nc * nz), M2((size_t)nc * nz);
+    std::vector<double> Hm((size_t)h.nHp * h.nzp, 0.0), M((size_t)nc * nz), M2((size_t)nc * nz);
     for (int r = 0; r < nc; ++r) for (int k = 0; k < nz; ++k) M[r * nz + k] = CMX(p->F_bar, nc, r, k);
     for (int i = 0; i <= p->Nu; ++i) {
         for (int r = 0; r < nc; ++r) for (int k = 0; k < nz; ++k) Hm[((size_t)i * nc + r) * h.nzp + k] = M[r * nz + k];
@@ -801,36 +808,77 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
     a.acc_bound = cfg->acc_bound; a.distance_error = cfg->distance_error;
     a.traj_trials = cfg->traj_trials; a.sampler_max_attempts = cfg->sampler_max_attempts;
     a.out = *out;
-    // T = 2 trials per lane once there are enough trials to fill the chip at that width
     hipStream_t st = (hipStream_t)stream;
     const char* env_t = getenv("LBMPC_MC_T");
-    // generic path: S rows broadcast from LDS; T = 2 trials per lane once 2-per-lane still fills every CU
-    const bool wide = env_t ? (atoi(env_t) == 2) : (cfg->trials >= (int64_t)256 * 8 * 128);
+    // T = 2 trials per lane once 2-per-lane still fills every CU
+    const bool wide = env_t ? (atoi(env_t) == 2) : (cfg->trials >= (int64_t)256 * 8 * 128 * 2);
     const int waves = pick_waves(c, 8);
     if (!waves) { set_error("constants (%zu B) do not fit in LDS", c->lds_const_bytes); return LBMPC_ERR_DIM; }
     const size_t lds = c->lds_const_bytes + (size_t)waves * ws_doubles(c->h.nz) * 8;
     const int per_block = waves * 64 * (wide ? 2 : 1);
-    int64_t blocks = (cfg->trials + per_block - 1) / per_block;
-    const int64_t resident = 256 * (int64_t)(LDS_LIMIT / lds > 4 ? 4 : (LDS_LIMIT / lds < 1 ? 1 : LDS_LIMIT / lds));
-    if (blocks > resident * 4) blocks = resident * 4;
-    dim3 grid((unsigned)blocks), blk(waves * 64);
+    // trial chunks: the pre-drawn disturbances of one chunk take steps * 2 nx * 8 B per trial
+    const size_t per_trial = (size_t)cfg->steps * 2 * c->h.nx * 8;
+    const char* env_g = getenv("LBMPC_MC_XI_GIB");
+    const double cap_gib = env_g ? atof(env_g) : 16.0;
+    int64_t chunk = cfg->trials;
+    if (per_trial > 0) {
+        const int64_t fit = (int64_t)(cap_gib * 1073741824.0 / (double)per_trial);
+        if (fit < chunk) chunk = fit < per_block ? per_block : fit / per_block * per_block;
+    }
+    if (chunk > cfg->trials) chunk = cfg->trials;
+    {
+        const size_t need = (size_t)chunk * per_trial;
+        if (need > c->xi_bytes) {
+            if (c->xi) LB_HIP(hipFree(c->xi));
+            c->xi = nullptr; c->xi_bytes = 0;
+            hipError_t e = hipMalloc((void**)&c->xi, need);
+            if (e != hipSuccess) { set_error("lbmpc_mc_run: %zu B of disturbance scratch -> %s (lower LBMPC_MC_XI_GIB)", need, hipGetErrorString(e)); return LBMPC_ERR_HIP; }
+            c->xi_bytes = need;
+        }
+        if ((size_t)chunk > c->xi_status_n) {
+            if (c->xi_status) LB_HIP(hipFree(c->xi_status));
+            c->xi_status = nullptr; c->xi_status_n = 0;
+            LB_HIP(hipMalloc((void**)&c->xi_status, (size_t)chunk * sizeof(int)));
+            c->xi_status_n = (size_t)chunk;
+        }
+    }
+    a.xi = c->xi; a.xi_status = c->xi_status;
+    for (int64_t c0 = 0; c0 < cfg->trials; c0 += chunk) {
+        const int64_t cn = cfg->trials - c0 < chunk ? cfg->trials - c0 : chunk;
+        a.chunk0 = c0; a.chunk_n = cn;
+        if (cfg->steps > 0) {
+            LB_HIP(hipMemsetAsync(c->xi_status, 0, (size_t)cn * sizeof(int), st));
+            dim3 sg((unsigned)((cn + 255) / 256), 2), sb(256);
+            switch (c->h.nx) {
+                case 1: hipLaunchKernelGGL((mc_sample_kernel<1>), sg, sb, 0, st, sd, cn, cfg->trial0 + c0, cfg->steps, cfg->seed, cfg->sampler_max_attempts, c->xi, c->xi_status); break;
+                case 2: hipLaunchKernelGGL((mc_sample_kernel<2>), sg, sb, 0, st, sd, cn, cfg->trial0 + c0, cfg->steps, cfg->seed, cfg->sampler_max_attempts, c->xi, c->xi_status); break;
+                case 3: hipLaunchKernelGGL((mc_sample_kernel<3>), sg, sb, 0, st, sd, cn, cfg->trial0 + c0, cfg->steps, cfg->seed, cfg->sampler_max_attempts, c->xi, c->xi_status); break;
+                default: hipLaunchKernelGGL((mc_sample_kernel<4>), sg, sb, 0, st, sd, cn, cfg->trial0 + c0, cfg->steps, cfg->seed, cfg->sampler_max_attempts, c->xi, c->xi_status); break;
+            }
+            LB_HIP(hipGetLastError());
+        }
+        int64_t blocks = (cn + per_block - 1) / per_block;
+        const int64_t resident = 256 * (int64_t)(LDS_LIMIT / lds > 4 ? 4 : (LDS_LIMIT / lds < 1 ? 1 : LDS_LIMIT / lds));
+        if (blocks > resident * 4) blocks = resident * 4;
+        dim3 grid((unsigned)blocks), blk(waves * 64);
 #define LAUNCH_MC(NXV, TV)                                                                      \
     do {                                                                                        \
         if (int rc = allow_lds(mc_kernel<NXV, TV>, lds)) return rc;                             \
         hipLaunchKernelGGL((mc_kernel<NXV, TV>), grid, blk, lds, st, c->d, sd, a);              \
     } while (0)
-    switch (c->h.nx * 2 + (wide ? 1 : 0)) {
-        case 2: LAUNCH_MC(1, 1); break;
-        case 3: LAUNCH_MC(1, 2); break;
-        case 4: LAUNCH_MC(2, 1); break;
-        case 5: LAUNCH_MC(2, 2); break;
-        case 6: LAUNCH_MC(3, 1); break;
-        case 7: LAUNCH_MC(3, 2); break;
-        case 8: LAUNCH_MC(4, 1); break;
-        default: LAUNCH_MC(4, 2); break;
-    }
+        switch (c->h.nx * 2 + (wide ? 1 : 0)) {
+            case 2: LAUNCH_MC(1, 1); break;
+            case 3: LAUNCH_MC(1, 2); break;
+            case 4: LAUNCH_MC(2, 1); break;
+            case 5: LAUNCH_MC(2, 2); break;
+            case 6: LAUNCH_MC(3, 1); break;
+            case 7: LAUNCH_MC(3, 2); break;
+            case 8: LAUNCH_MC(4, 1); break;
+            default: LAUNCH_MC(4, 2); break;
+        }
 #undef LAUNCH_MC
-    LB_HIP(hipGetLastError());
+        LB_HIP(hipGetLastError());
+    }
     return 0;
 }
 

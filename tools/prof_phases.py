@@ -27,3 +27,8 @@ for i, n in enumerate(names):
 print(f"  flagged solves {v[4]:.0f}  group rounds {v[5]:.0f}  mean iters/trial {np.mean(out['qp_iters']):.2f}")
 if v[5] > 0:
     print(f"  cycles per group round {v[2]/v[5]:.0f}")
+g = v[8:16]
+print("  solver: scan %.1f%%  step2 %.1f%%  add %.1f%%  drop %.1f%% of solve; loop trips %.0f scans %.0f drop-phases %.0f" % (
+    g[0] / v[2] * 100, g[1] / v[2] * 100, g[2] / v[2] * 100, g[3] / v[2] * 100, g[4], g[5], g[6]))
+if g[4] > 0:
+    print("  cycles: per scan %.0f  per step2 %.0f  per add %.0f  per drop-phase %.0f" % (g[0] / max(g[5], 1), g[1] / g[4], g[2] / g[4], g[3] / max(g[6], 1)))
