@@ -155,9 +155,9 @@ __device__ __forceinline__ void scan_rows(const CtxDev* __restrict__ C, const Ld
             eval(B, m + 1);
         }
     }
-    // ---- H rows (storage padded to a multiple of 128 rows; rows >= nH are skipped), two QPs per pass ----
+    // ---- H rows (row index clamped for the loads; rows >= nH are skipped), two QPs per pass ----
     {
-        const int nchH = C->nHp >> 6;
+        const int nchH = ((nH + 127) >> 7) << 1;  // even
         const int nz4 = (nz + 3) >> 2;
 #pragma unroll
         for (int g0 = 0; g0 < 4; g0 += 2) {
@@ -168,10 +168,11 @@ __device__ __forceinline__ void scan_rows(const CtxDev* __restrict__ C, const Ld
                 for (int k = 0; k < NZMAX; ++k) zu[gg][k] = (k < 4 * nz4) ? readlane_f64(my_z, 16 * (g0 + gg) + k) : 0.0;
             int r = lane % nc;
             const int rstep = 64 % nc;
-            const double* hb = L.Hm + lane * nzp;
+            const double* hb = L.Hm;
             double rowA[NZMAX], rowB[NZMAX];
             auto fetch = [&](double* dst, int m) {
-                const double* hp = hb + m * 64 * nzp;
+                const int hr = lane + 64 * m;
+                const double* hp = hb + (hr < nH ? hr : nH - 1) * nzp;
 #pragma unroll
                 for (int k4 = 0; k4 < NZMAX / 4; ++k4)
                     if (k4 < nz4) {

@@ -16,6 +16,7 @@
 //     Cholesky factor / KKT vectors live in a per-wave LDS workspace and registers;
 //   * phase C (lane-per-trial): u = K x + c_0, plant update, violation flags.
 // Constants ([S_b | S_A] rows, F_bar Psi^i rows, (2P)^-1) are staged once per block into LDS.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -32,7 +33,7 @@ namespace lbmpc {
 #define NZMAX LBMPC_MAX_NZ
 
 struct CtxDev {
-    int nx, nu, N, nc, Nu, nS, nW, nz, nH, RL, nzp, nSp, nHp;  // nSp, nHp: S / H row storage padded to a multiple of 128
+    int nx, nu, N, nc, Nu, nS, nW, nz, nH, RL, nzp, nSp;  // nSp: S row storage padded to a multiple of 128
     double A[LBMPC_MAX_NX * LBMPC_MAX_NX];    // row-major
     double B[LBMPC_MAX_NX * LBMPC_MAX_NU];    // row-major nx x nu
     double K[LBMPC_MAX_NU * LBMPC_MAX_NX];    // row-major nu x nx
@@ -41,6 +42,12 @@ struct CtxDev {
     double hs[LBMPC_MAX_NC];
     BoxW box;
     const double* Srow;  // nSp x RL : [S_b[j], S_A[j,0..nx-1]], RL = nx + 1
+    const float* S32;    // fp32 copy for the first-pass filter, row PAIRS interleaved: [b_j b_j+1 a_j0 a_j+1,0 ...]
+    double amax[LBMPC_MAX_NX], bmax;  // max_j |S_A[j,k]|, max_j |S_b[j]|: rounding margin of the filter
+    // inscribed ellipsoid E = {x : x' ME x <= 1} of S (centred at 0): q' ME q <= (alpha (1-1e-6))^2 proves that no S
+    // row is violated at z = 0 (Cauchy-Schwarz: |a_j.q| <= sqrt(a_j' ME^-1 a_j) sqrt(q' ME q) <= b_j alpha (1-1e-6))
+    double ME[LBMPC_MAX_NX * LBMPC_MAX_NX], bmin;
+    int hasE;
     const double* Hm;    // nH x nzp: rows of F_bar Psi^i, i = 0..Nu
     const double* Ginv;  // nz x nz : (2 blkdiag(Px,Pc))^-1
 };
@@ -51,6 +58,7 @@ struct lbmpc_ctx {
     lbmpc::CtxDev h;          // host copy (device pointers inside)
     lbmpc::CtxDev* d = nullptr;
     double *dS = nullptr, *dH = nullptr, *dG = nullptr;
+    float* dS32 = nullptr;
     int device = 0;
     size_t lds_const_bytes = 0;
     // grow-only scratch of lbmpc_mc_run: pre-drawn step disturbances of one trial chunk (+ their cap flags)
@@ -66,7 +74,13 @@ struct LdsView {
     const double* Srow;
     const double* Hm;
     const double* Ginv;
+    const float* S32;
 };
+// LDS layout (doubles): [S rows | H rows | Ginv | pad to even | S32 (floats) | per-wave solver slots]
+__host__ __device__ inline int lds_const_doubles(const CtxDev& h) {
+    const int d64 = (h.nSp * h.RL + h.nH * h.nzp + h.nz * h.nz + 1) & ~1;
+    return d64 + (h.nSp * h.RL + 1) / 2;
+}
 __host__ __device__ inline int ws_doubles(int) { return 4 * 48; }  // GWS_PER_WAVE: four row slots per wave
 
 }  // namespace lbmpc
@@ -147,61 +161,112 @@ __device__ __forceinline__ double hk_value(const CtxDev* __restrict__ C, double 
 // the S rows (each row one LDS broadcast, shared by the 64*T trials of the wave); the H rows contribute
 // exactly 1-h_k[r] at z = 0.  Only "is any row violated" is needed here: the pivot itself is found by
 // the cooperative solver, which recomputes the same values.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// One chunk of 8 rows (4 interleaved row pairs), packed fp32: per pair 1 pk_mul + NX pk_fma + 1 min3.
 template <int NX, int T>
-__device__ __forceinline__ void first_pass_eval(const double2* cur, const double* alpha, const double (*q)[NX], double* mn) {
-    constexpr int RLc = NX + 1, CH = 4 * RLc / 2;
-    double cf[4 * RLc];
+__device__ __forceinline__ void first_pass_eval(const float4* cur, const float* af, const float (*qf)[NX], float* mn) {
+    constexpr int RLc = NX + 1, CH = 2 * RLc;  // float4 loads per chunk
+    float cf[8 * RLc];
 #pragma unroll
-    for (int i = 0; i < CH; ++i) { cf[2 * i] = cur[i].x; cf[2 * i + 1] = cur[i].y; }
+    for (int i = 0; i < CH; ++i) { cf[4 * i] = cur[i].x; cf[4 * i + 1] = cur[i].y; cf[4 * i + 2] = cur[i].z; cf[4 * i + 3] = cur[i].w; }
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-        double acc[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            acc[r] = alpha[t] * cf[r * RLc];
+        for (int pr = 0; pr < 4; ++pr) {
+            const float* r = cf + pr * 2 * RLc;
+            f32x2 acc = (f32x2){af[t], af[t]} * (f32x2){r[0], r[1]};
 #pragma unroll
-            for (int k = 0; k < NX; ++k) acc[r] = fma(cf[r * RLc + 1 + k], q[t][k], acc[r]);
+            for (int k = 0; k < NX; ++k)
+                acc = __builtin_elementwise_fma((f32x2){r[2 + 2 * k], r[3 + 2 * k]}, (f32x2){qf[t][k], qf[t][k]}, acc);
+            mn[t] = __builtin_fminf(__builtin_fminf(acc.x, acc.y), mn[t]);
         }
-        mn[t] = __builtin_fmin(mn[t], __builtin_fmin(__builtin_fmin(acc[0], acc[1]), __builtin_fmin(acc[2], acc[3])));
     }
 }
 
+// First pass at z = 0 for the T trials of this lane: is any S row violated?  slack_j = alpha S_b[j] + S_A[j,:].q ; the
+// H rows contribute exactly 1-h_k[r] (min_omh, exact).  This is only a FILTER in front of the exact solver (whose
+// own fp64 scan decides, and returns z = 0 after zero iterations when nothing is violated), so it runs in packed
+// fp32 -- every row pair is one LDS broadcast shared by the 64*T trials of the wave -- and flags a trial whenever
+// the fp32 minimum is below -tol + margin, margin = 2^-20 (alpha max|S_b| + sum_k max|S_A[:,k]| |q_k|) >= twice the
+// worst-case rounding error (gamma_7, u = 2^-24) of any row.  A violated row is therefore never missed; a false
+// alarm costs one scan.  NaN / overflow compare as "flagged".
 template <int NX, int T>
 __device__ __forceinline__ void first_pass(const CtxDev* __restrict__ C, const LdsView& L, const double* alpha,
                                            const double (*q)[NX], const double* min_omh, bool* need) {
-    constexpr int RLc = NX + 1;        // == C->RL
-    constexpr int CH = 4 * RLc / 2;    // double2 loads per chunk of 4 rows
-    double mn[T];
+    constexpr int RLc = NX + 1;
+    constexpr int CH = 2 * RLc;
+    float mn[T], af[T], qf[T][NX];
+    double thresh[T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) mn[t] = min_omh[t];
-    const int nch = C->nSp >> 2;       // even: nSp is a multiple of 8
-    const double2* p = reinterpret_cast<const double2*>(L.Srow);
-    double2 bufA[CH], bufB[CH];
+    for (int t = 0; t < T; ++t) {
+        mn[t] = __builtin_inff();
+        af[t] = (float)alpha[t];
+        double e = fabs(alpha[t]) * C->bmax;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) { qf[t][k] = (float)q[t][k]; e = fma(C->amax[k], fabs(q[t][k]), e); }
+        thresh[t] = -QP_TOL_VIOL + 0x1p-20 * e;
+    }
+    // ellipsoid early-out: when every trial of the wave lies inside alpha (1-1e-6) E there is nothing to scan
+    {
+        bool outside = false;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            double e2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double ti = 0.0;
+#pragma unroll
+                for (int k = 0; k < NX; ++k) ti = fma(C->ME[i * NX + k], q[t][k], ti);
+                e2 = fma(q[t][i], ti, e2);
+            }
+            const double as = alpha[t] * (1.0 - 1e-6);
+            // slack_j >= alpha 1e-6 b_j must clear the tolerance and the rounding of the exact evaluation
+            const bool inside = C->hasE && alpha[t] * 1e-6 * C->bmin >= 1e-9 && e2 <= as * as;
+            outside = outside || !inside;
+        }
+        if (__builtin_amdgcn_ballot_w64(outside) == 0) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) need[t] = min_omh[t] < -QP_TOL_VIOL;
+            return;
+        }
+    }
+    const int nch = C->nSp >> 3;       // chunks of 8 rows; even: nSp is a multiple of 128
+    const float4* p = reinterpret_cast<const float4*>(L.S32);
+    float4 bufA[CH], bufB[CH];
 #pragma unroll
     for (int i = 0; i < CH; ++i) bufA[i] = p[i];
-    // ping-pong: the next chunk of 4 rows is in flight while the current one is evaluated
+    // ping-pong: the next chunk is in flight while the current one is evaluated
     for (int c = 0; c < nch; c += 2) {
-        const double2* pb = p + (size_t)(c + 1) * CH;
+        const float4* pb = p + (size_t)(c + 1) * CH;
 #pragma unroll
         for (int i = 0; i < CH; ++i) bufB[i] = pb[i];
         __builtin_amdgcn_sched_barrier(0);
-        first_pass_eval<NX, T>(bufA, alpha, q, mn);
-        const double2* pa = p + (size_t)(c + 2 < nch ? c + 2 : 0) * CH;
+        first_pass_eval<NX, T>(bufA, af, qf, mn);
+        const float4* pa = p + (size_t)(c + 2 < nch ? c + 2 : 0) * CH;
 #pragma unroll
         for (int i = 0; i < CH; ++i) bufA[i] = pa[i];
         __builtin_amdgcn_sched_barrier(0);
-        first_pass_eval<NX, T>(bufB, alpha, q, mn);
+        first_pass_eval<NX, T>(bufB, af, qf, mn);
     }
 #pragma unroll
-    for (int t = 0; t < T; ++t) need[t] = mn[t] < -QP_TOL_VIOL;
+    for (int t = 0; t < T; ++t) need[t] = (min_omh[t] < -QP_TOL_VIOL) || !((double)mn[t] >= thresh[t]);
 }
 
-__device__ __forceinline__ void stage_constants(const CtxDev* __restrict__ C, double* lds) {
-    const int nS_RL = C->nSp * C->RL, nH_nzp = C->nHp * C->nzp, nzz = C->nz * C->nz;
+// Copies the constants into LDS and returns the view; *ws_base = first per-wave solver slot.
+__device__ __forceinline__ LdsView stage_constants(const CtxDev* __restrict__ C, double* lds, double** ws_base) {
+    const int nS_RL = C->nSp * C->RL, nH_nzp = C->nH * C->nzp, nzz = C->nz * C->nz;
+    const int d64 = (nS_RL + nH_nzp + nzz + 1) & ~1;
+    float* s32 = reinterpret_cast<float*>(lds + d64);
     for (int i = threadIdx.x; i < nS_RL; i += blockDim.x) lds[i] = C->Srow[i];
     for (int i = threadIdx.x; i < nH_nzp; i += blockDim.x) lds[nS_RL + i] = C->Hm[i];
     for (int i = threadIdx.x; i < nzz; i += blockDim.x) lds[nS_RL + nH_nzp + i] = C->Ginv[i];
+    for (int i = threadIdx.x; i < nS_RL; i += blockDim.x) s32[i] = C->S32[i];
     __syncthreads();
+    LdsView L;
+    L.Srow = lds; L.Hm = lds + nS_RL; L.Ginv = L.Hm + nH_nzp; L.S32 = s32;
+    *ws_base = lds + lds_const_doubles(*C);
+    return L;
 }
 
 // Solve the QPs of the lanes flagged in `need`, four at a time (one per 16-lane row of the wave).
@@ -277,12 +342,11 @@ struct StepIO {
 template <int NX>
 __global__ __launch_bounds__(256) void uqmpc_step_kernel(const CtxDev* __restrict__ C, int64_t batch, int uq, StepIO io) {
     extern __shared__ double lds[];
-    stage_constants(C, lds);
-    LdsView L;
-    L.Srow = lds; L.Hm = lds + C->nSp * C->RL; L.Ginv = L.Hm + C->nHp * C->nzp;
+    double* ws_base;
+    const LdsView L = stage_constants(C, lds, &ws_base);
     const int wave = threadIdx.x / LB_WAVE, nwaves = blockDim.x / LB_WAVE, lane = lane_id();
     const int nz = C->nz, ncv = nz - NX;
-    double* ws = lds + C->nSp * C->RL + C->nHp * C->nzp + nz * nz + wave * ws_doubles(nz);
+    double* ws = ws_base + wave * ws_doubles(nz);
     for (int64_t base = ((int64_t)blockIdx.x * nwaves + wave) * LB_WAVE; base < batch;
          base += (int64_t)gridDim.x * nwaves * LB_WAVE) {
         const int64_t b = base + lane;
@@ -428,12 +492,11 @@ __device__ unsigned long long lbmpc_prof[16];
 template <int NX, int T>
 __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, SamplerDev smp, McArgs a) {
     extern __shared__ double lds[];
-    stage_constants(C, lds);
-    LdsView L;
-    L.Srow = lds; L.Hm = lds + C->nSp * C->RL; L.Ginv = L.Hm + C->nHp * C->nzp;
+    double* ws_base;
+    const LdsView L = stage_constants(C, lds, &ws_base);
     const int wave = threadIdx.x / LB_WAVE, nwaves = blockDim.x / LB_WAVE, lane = lane_id();
     const int nz = C->nz, nu = C->nu, K = a.steps;
-    double* ws = lds + C->nSp * C->RL + C->nHp * C->nzp + nz * nz + wave * ws_doubles(nz);
+    double* ws = ws_base + wave * ws_doubles(nz);
     const SamplerDev* S = &smp;
 #ifdef LBMPC_PROFILE
     long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -622,12 +685,62 @@ using namespace lbmpc;
 
 #define CMX(M, rows, i, j) ((M)[(size_t)(i) + (size_t)(rows) * (size_t)(j)])
 
+// Inscribed ellipsoid of S about the origin (used only to skip provably empty row scans; see CtxDev::ME).
+// E = polar of the minimum-volume enclosing ellipsoid of the points +-a_j/b_j (Khachiyan's algorithm, stopped early:
+// tightness is all that depends on convergence), then rescaled so that sqrt(a_j' ME^-1 a_j) <= b_j holds for the
+// matrix actually stored.  hasE = 0 when 0 is not interior or the points do not span R^nx.
+static void inscribed_ellipsoid(int nx, int nS, const double* S_A /* col-major */, const double* S_b, lbmpc::CtxDev* h) {
+    h->hasE = 0; h->bmin = 0.0;
+    for (int i = 0; i < LBMPC_MAX_NX * LBMPC_MAX_NX; ++i) h->ME[i] = 0.0;
+    double bmin = 1e300;
+    for (int j = 0; j < nS; ++j) bmin = std::min(bmin, S_b[j]);
+    if (!(bmin > 0.0) || nS < nx) return;
+    std::vector<double> P((size_t)nS * nx), u((size_t)nS, 1.0 / nS), g((size_t)nS);
+    for (int j = 0; j < nS; ++j) for (int k = 0; k < nx; ++k) P[(size_t)j * nx + k] = CMX(S_A, nS, j, k) / S_b[j];
+    double X[16], Xi[16];
+    auto moment = [&]() {
+        for (int i = 0; i < nx * nx; ++i) X[i] = 0.0;
+        for (int j = 0; j < nS; ++j) for (int a = 0; a < nx; ++a) for (int b = 0; b < nx; ++b) X[a * nx + b] += u[j] * P[(size_t)j * nx + a] * P[(size_t)j * nx + b];
+        return invert_gj(nx, X, Xi);
+    };
+    for (int it = 0; it < 3000; ++it) {
+        if (!moment()) return;
+        int jm = 0; double gm = -1.0;
+        for (int j = 0; j < nS; ++j) {
+            double acc = 0.0;
+            for (int a = 0; a < nx; ++a) { double t = 0.0; for (int b = 0; b < nx; ++b) t += Xi[a * nx + b] * P[(size_t)j * nx + b]; acc += P[(size_t)j * nx + a] * t; }
+            if (acc > gm) { gm = acc; jm = j; }
+        }
+        if (gm - nx < 1e-3 * nx) break;
+        const double step = (gm - nx) / (nx * (gm - 1.0));
+        for (int j = 0; j < nS; ++j) u[j] *= (1.0 - step);
+        u[jm] += step;
+    }
+    if (!moment()) return;
+    // enclosing ellipsoid of the points: y' (Xi / nx) y <= (about) 1;  E: x' (nx X) x <= 1, with ME^-1 = Xi / nx
+    double ME[16], MEi[16];
+    for (int i = 0; i < nx * nx; ++i) ME[i] = nx * X[i];
+    for (int a = 0; a < nx; ++a) for (int b = a + 1; b < nx; ++b) { const double sy = 0.5 * (ME[a * nx + b] + ME[b * nx + a]); ME[a * nx + b] = ME[b * nx + a] = sy; }
+    if (!invert_gj(nx, ME, MEi)) return;
+    double r2 = 0.0;  // max_j a_j' ME^-1 a_j / b_j^2
+    for (int j = 0; j < nS; ++j) {
+        double acc = 0.0;
+        for (int a = 0; a < nx; ++a) { double t = 0.0; for (int b = 0; b < nx; ++b) t += MEi[a * nx + b] * P[(size_t)j * nx + b]; acc += P[(size_t)j * nx + a] * t; }
+        r2 = std::max(r2, acc);
+    }
+    if (!(r2 > 0.0) || !std::isfinite(r2)) return;
+    for (int i = 0; i < nx * nx; ++i) h->ME[i] = ME[i] * r2 * (1.0 + 1e-9);  // shrink E until it is inside S
+    h->bmin = bmin;
+    h->hasE = 1;
+}
+
 extern "C" void lbmpc_destroy(lbmpc_ctx* c) {
     if (!c) return;
     if (c->d) (void)hipFree(c->d);
     if (c->dS) (void)hipFree(c->dS);
     if (c->dH) (void)hipFree(c->dH);
     if (c->dG) (void)hipFree(c->dG);
+    if (c->dS32) (void)hipFree(c->dS32);
     if (c->xi) (void)hipFree(c->xi);
     if (c->xi_status) (void)hipFree(c->xi_status);
     delete c;
@@ -653,7 +766,6 @@ extern "C" int lbmpc_uqmpc_create(const lbmpc_params* p, lbmpc_ctx** out) {
     h.nx = nx; h.nu = nu; h.N = N; h.nc = nc; h.Nu = p->Nu; h.nS = nS; h.nW = p->nW; h.nz = nz; h.nH = nH;
     h.RL = nx + 1;              // [S_b, S_A row]; chunks of 4 rows are read as double2 broadcasts
     h.nSp = (nS + 127) & ~127;  // pad rows can never be violated
-    h.nHp = (nH + 127) & ~127;  // zero rows, skipped by index
     h.nzp = ((nz + 3) & ~3) | 1;  // odd pitch: conflict-free per-lane row reads
     for (int i = 0; i < nx; ++i) for (int j = 0; j < nx; ++j) h.A[i * nx + j] = CMX(p->A, nx, i, j);
     for (int i = 0; i < nx; ++i) for (int j = 0; j < nu; ++j) h.B[i * nu + j] = CMX(p->B, nx, i, j);
@@ -689,8 +801,22 @@ extern "C" int lbmpc_uqmpc_create(const lbmpc_params* p, lbmpc_ctx** out) {
     std::vector<double> Srow((size_t)h.nSp * h.RL, 0.0);
     for (int j = nS; j < h.nSp; ++j) Srow[(size_t)j * h.RL] = 1e300;
     for (int j = 0; j < nS; ++j) { Srow[(size_t)j * h.RL] = p->S_b[j]; for (int k = 0; k < nx; ++k) Srow[(size_t)j * h.RL + 1 + k] = CMX(p->S_A, nS, j, k); }
+    // fp32 filter copy, row pairs interleaved; pad rows: b = 3e38, a = 0
+    std::vector<float> S32((size_t)h.nSp * h.RL, 0.0f);
+    h.bmax = 0.0;
+    for (int k = 0; k < LBMPC_MAX_NX; ++k) h.amax[k] = 0.0;
+    for (int j = 0; j < h.nSp; ++j) {
+        float* pr = S32.data() + (size_t)(j >> 1) * 2 * h.RL + (j & 1);
+        pr[0] = j < nS ? (float)p->S_b[j] : 3.0e38f;
+        for (int k = 0; k < nx; ++k) pr[2 + 2 * k] = j < nS ? (float)CMX(p->S_A, nS, j, k) : 0.0f;
+        if (j < nS) {
+            h.bmax = std::max(h.bmax, std::fabs(p->S_b[j]));
+            for (int k = 0; k < nx; ++k) h.amax[k] = std::max(h.amax[k], std::fabs(CMX(p->S_A, nS, j, k)));
+        }
+    }
+    inscribed_ellipsoid(nx, nS, p->S_A, p->S_b, &h);
     // H rows: F_bar Psi^i, i = 0..Nu  (UQRobustMPC.m:153-155)
-    std::vector<double> Hm((size_t)h.nHp * h.nzp, 0.0), M((size_t)nc * nz), M2((size_t)nc * nz);
+    std::vector<double> Hm((size_t)nH * h.nzp, 0.0), M((size_t)nc * nz), M2((size_t)nc * nz);
     for (int r = 0; r < nc; ++r) for (int k = 0; k < nz; ++k) M[r * nz + k] = CMX(p->F_bar, nc, r, k);
     for (int i = 0; i <= p->Nu; ++i) {
         for (int r = 0; r < nc; ++r) for (int k = 0; k < nz; ++k) Hm[((size_t)i * nc + r) * h.nzp + k] = M[r * nz + k];
@@ -707,13 +833,15 @@ extern "C" int lbmpc_uqmpc_create(const lbmpc_params* p, lbmpc_ctx** out) {
     if ((e = hipMalloc((void**)&c->dS, Srow.size() * 8)) != hipSuccess) return fail(e, "hipMalloc");
     if ((e = hipMalloc((void**)&c->dH, Hm.size() * 8)) != hipSuccess) return fail(e, "hipMalloc");
     if ((e = hipMalloc((void**)&c->dG, Ginv.size() * 8)) != hipSuccess) return fail(e, "hipMalloc");
+    if ((e = hipMalloc((void**)&c->dS32, S32.size() * 4)) != hipSuccess) return fail(e, "hipMalloc");
+    if ((e = hipMemcpy(c->dS32, S32.data(), S32.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
     if ((e = hipMalloc((void**)&c->d, sizeof(CtxDev))) != hipSuccess) return fail(e, "hipMalloc");
     if ((e = hipMemcpy(c->dS, Srow.data(), Srow.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
     if ((e = hipMemcpy(c->dH, Hm.data(), Hm.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
     if ((e = hipMemcpy(c->dG, Ginv.data(), Ginv.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
-    h.Srow = c->dS; h.Hm = c->dH; h.Ginv = c->dG;
+    h.Srow = c->dS; h.Hm = c->dH; h.Ginv = c->dG; h.S32 = c->dS32;
     if ((e = hipMemcpy(c->d, &h, sizeof(CtxDev), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
-    c->lds_const_bytes = (Srow.size() + Hm.size() + Ginv.size()) * 8;
+    c->lds_const_bytes = (size_t)lds_const_doubles(h) * 8;
     *out = c;
     return 0;
 }
