@@ -251,6 +251,13 @@ int lbmpc_mc_run(lbmpc_ctx* ctx, const lbmpc_sampler* smp, const lbmpc_mc_cfg* c
 int lbmpc_mc_run_dev(lbmpc_ctx* ctx, const lbmpc_sampler* smp, const lbmpc_mc_cfg* cfg,
                      lbmpc_mc_out* out_dev, void* stream);
 
+/* Work counters of the last lbmpc_mc_run / lbmpc_mc_run_dev on this context (synchronises the device).  No
+ * counterpart in the reference (its loops are timed with tic/toc, Case_3...:57,69); used by bench.py to state the
+ * arithmetic that was actually executed.  out[0] wave-steps whose rows were scanned by the fp32 filter (64 trials
+ * each), out[1] wave-steps in total, out[2] QP solves, out[3] solver rounds (up to 4 QPs each), out[4] solver loop
+ * trips, out[5] pivot scans (4 QPs each), out[6..7] reserved. */
+int lbmpc_mc_counters(lbmpc_ctx* ctx, uint64_t* out8);
+
 #ifdef __cplusplus
 }
 #endif

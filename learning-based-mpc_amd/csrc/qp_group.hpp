@@ -269,7 +269,8 @@ __device__ __forceinline__ void chol_append_row(const CtxDev* __restrict__ C, co
 // gws: this ROW's LDS slot (omh filled by the caller; results written at the end).
 template <int NX>
 __device__ __forceinline__ void group_qp_solve(const CtxDev* __restrict__ C, const LdsView& L, double* gws, bool live,
-                                               double alpha, const double* q, long long* prof = nullptr) {
+                                               double alpha, const double* q, unsigned* ctr /* [0] trips, [1] scans (wave-uniform) */,
+                                               long long* prof = nullptr) {
 #ifdef LBMPC_PROFILE
 #define GP_T(var) const long long var = clock64()
 #define GP_ADD(slot, t0, t1) prof[slot] += (t1) - (t0)
@@ -297,8 +298,10 @@ __device__ __forceinline__ void group_qp_solve(const CtxDev* __restrict__ C, con
         const bool need_scan = !done && !have_p;
         GP_T(g0);
         GP_INC(4);
+        ctr[0] += 1;
         if (__builtin_amdgcn_ballot_w64(need_scan) != 0) {
             GP_INC(5);
+            ctr[1] += 1;
             double best = -QP_TOL_VIOL;
             int bj = 0x7fffffff;
             scan_rows<NX>(C, L, gws - grp * GWS_DOUBLES, alpha, q, my_z, actS, actH, best, bj);

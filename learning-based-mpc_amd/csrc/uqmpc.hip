@@ -66,6 +66,7 @@ struct lbmpc_ctx {
     size_t xi_bytes = 0;
     int* xi_status = nullptr;
     size_t xi_status_n = 0;
+    unsigned long long* counters = nullptr;  // 8 work counters of the last mc_run
 };
 
 namespace lbmpc {
@@ -192,7 +193,7 @@ __device__ __forceinline__ void first_pass_eval(const float4* cur, const float* 
 // worst-case rounding error (gamma_7, u = 2^-24) of any row.  A violated row is therefore never missed; a false
 // alarm costs one scan.  NaN / overflow compare as "flagged".
 template <int NX, int T>
-__device__ __forceinline__ void first_pass(const CtxDev* __restrict__ C, const LdsView& L, const double* alpha,
+__device__ __forceinline__ bool first_pass(const CtxDev* __restrict__ C, const LdsView& L, const double* alpha,
                                            const double (*q)[NX], const double* min_omh, bool* need) {
     constexpr int RLc = NX + 1;
     constexpr int CH = 2 * RLc;
@@ -228,7 +229,7 @@ __device__ __forceinline__ void first_pass(const CtxDev* __restrict__ C, const L
         if (__builtin_amdgcn_ballot_w64(outside) == 0) {
 #pragma unroll
             for (int t = 0; t < T; ++t) need[t] = min_omh[t] < -QP_TOL_VIOL;
-            return;
+            return false;
         }
     }
     const int nch = C->nSp >> 3;       // chunks of 8 rows; even: nSp is a multiple of 128
@@ -251,6 +252,7 @@ __device__ __forceinline__ void first_pass(const CtxDev* __restrict__ C, const L
     }
 #pragma unroll
     for (int t = 0; t < T; ++t) need[t] = (min_omh[t] < -QP_TOL_VIOL) || !((double)mn[t] >= thresh[t]);
+    return true;  // the rows were scanned
 }
 
 // Copies the constants into LDS and returns the view; *ws_base = first per-wave solver slot.
@@ -276,10 +278,13 @@ __device__ __forceinline__ void solve_flagged(const CtxDev* __restrict__ C, cons
                                               bool need, double alpha, const double* v, const double* q,
                                               double* s0, double* c0, int& status, int& iters,
                                               int* nact_out, int* act_out /* NZMAX, sorted, or null */,
-                                              double* c_full /* nz-NX or null */, long long* prof = nullptr) {
+                                              double* c_full /* nz-NX or null */, unsigned* ctr /* [0] solves [1] rounds [2] trips [3] scans */,
+                                              long long* prof = nullptr) {
     const int lane = lane_id(), grp = lane >> 4;
     uint64_t mask = __builtin_amdgcn_ballot_w64(need);
+    ctr[0] += (unsigned)__builtin_popcountll(mask);
     while (mask) {
+        ctr[1] += 1;
         int src[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -304,7 +309,7 @@ __device__ __forceinline__ void solve_flagged(const CtxDev* __restrict__ C, cons
         if (mygrp >= 0)
             for (int r = 0; r < C->nc; ++r) wws[mygrp * GWS_DOUBLES + r] = 1.0 - hk_value<NX>(C, alpha, v, r);
         wave_sync();
-        group_qp_solve<NX>(C, L, wws + grp * GWS_DOUBLES, live, a_g, q_g, prof);
+        group_qp_solve<NX>(C, L, wws + grp * GWS_DOUBLES, live, a_g, q_g, ctr + 2, prof);
         wave_sync();
         if (mygrp >= 0) {
             const double* gw = wws + mygrp * GWS_DOUBLES;
@@ -371,8 +376,9 @@ __global__ __launch_bounds__(256) void uqmpc_step_kernel(const CtxDev* __restric
         double* cdst = (valid && io.c) ? io.c + b * ncv : nullptr;
         if (cdst) for (int k = 0; k < ncv; ++k) cdst[k] = 0.0;
         if (valid && io.active_set) for (int a = 0; a < NZMAX; ++a) io.active_set[b * NZMAX + a] = -1;
+        unsigned ctr[4] = {0, 0, 0, 0};
         solve_flagged<NX>(C, L, ws, valid && need[0], alpha[0], v, q[0], s0, c0, status, iters,
-                          &nact, (valid && io.active_set) ? io.active_set + b * NZMAX : nullptr, cdst);
+                          &nact, (valid && io.active_set) ? io.active_set + b * NZMAX : nullptr, cdst, ctr);
         (void)act_sorted;
         if (!valid) continue;
         if (io.s0) for (int k = 0; k < NX; ++k) io.s0[b * NX + k] = s0[k];
@@ -426,6 +432,7 @@ struct McArgs {
     int64_t chunk0, chunk_n;
     const double* xi;       // [step][chunk trial][LV nx | EV nx]
     const int* xi_status;   // [chunk trial] LBMPC_ST_SAMPLER_CAP if a step sampler hit the attempt cap
+    unsigned long long* counters;  // 8 work counters of this launch
     lbmpc_mc_out out;
 };
 
@@ -498,6 +505,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
     const int nz = C->nz, nu = C->nu, K = a.steps;
     double* ws = ws_base + wave * ws_doubles(nz);
     const SamplerDev* S = &smp;
+    unsigned ctr[6] = {0, 0, 0, 0, 0, 0};  // wave-uniform work counters (lbmpc_mc_counters)
 #ifdef LBMPC_PROFILE
     long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     PROF_T(pk0);
@@ -566,7 +574,8 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
                 tighten<NX>(C, alpha[t], v[t], x[t], q[t], momh[t], aomh[t]);
             }
             PROF_T(p1);
-            first_pass<NX, T>(C, L, alpha, q, momh, need);
+            ctr[0] += first_pass<NX, T>(C, L, alpha, q, momh, need) ? T : 0;
+            ctr[1] += T;
             PROF_T(p2);
             PROF_ADD(0, p0, p1); PROF_ADD(1, p1, p2);
 #pragma unroll
@@ -582,7 +591,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
                 prof[5] += (__builtin_popcountll(__builtin_amdgcn_ballot_w64(valid[t] && need[t])) + 3) >> 2;
 #endif
                 solve_flagged<NX>(C, L, ws, valid[t] && need[t], alpha[t], v[t], q[t], s0, c0,
-                                  status[t], iters[t], nullptr, nullptr, nullptr, PROF_PTR);
+                                  status[t], iters[t], nullptr, nullptr, nullptr, ctr + 2, PROF_PTR);
                 PROF_T(p4);
                 PROF_ADD(2, p3, p4);
                 // u = K x + c(1:nu); EVModeling (ModelingCar.m:36-37); relative dynamics
@@ -641,6 +650,8 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
             if (a.out.x_final) for (int i = 0; i < NX; ++i) a.out.x_final[l * NX + i] = x[t][i];
         }
     }
+    if (lane == 0 && a.counters)
+        for (int i = 0; i < 6; ++i) atomicAdd(a.counters + i, (unsigned long long)ctr[i]);
 #ifdef LBMPC_PROFILE
     PROF_T(pk1);
     prof[6] = pk1 - pk0;
@@ -743,6 +754,7 @@ extern "C" void lbmpc_destroy(lbmpc_ctx* c) {
     if (c->dS32) (void)hipFree(c->dS32);
     if (c->xi) (void)hipFree(c->xi);
     if (c->xi_status) (void)hipFree(c->xi_status);
+    if (c->counters) (void)hipFree(c->counters);
     delete c;
 }
 
@@ -970,7 +982,9 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
             c->xi_status_n = (size_t)chunk;
         }
     }
-    a.xi = c->xi; a.xi_status = c->xi_status;
+    if (!c->counters) LB_HIP(hipMalloc((void**)&c->counters, 8 * sizeof(unsigned long long)));
+    LB_HIP(hipMemsetAsync(c->counters, 0, 8 * sizeof(unsigned long long), st));
+    a.xi = c->xi; a.xi_status = c->xi_status; a.counters = c->counters;
     for (int64_t c0 = 0; c0 < cfg->trials; c0 += chunk) {
         const int64_t cn = cfg->trials - c0 < chunk ? cfg->trials - c0 : chunk;
         a.chunk0 = c0; a.chunk_n = cn;
@@ -1007,6 +1021,16 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
 #undef LAUNCH_MC
         LB_HIP(hipGetLastError());
     }
+    return 0;
+}
+
+extern "C" int lbmpc_mc_counters(lbmpc_ctx* c, uint64_t* out8) {
+    if (int rc = check_device()) return rc;
+    if (!c || !out8) { set_error("lbmpc_mc_counters: null argument"); return LBMPC_ERR_ARG; }
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    if (!c->counters) return 0;
+    LB_HIP(hipDeviceSynchronize());
+    LB_HIP(hipMemcpy(out8, c->counters, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -129,6 +129,7 @@ def declare(lib, prefix):
         for name in ["support_batch", "halfspace_max", "sample_information_sets", "homothety_lp", "mc_run"]:
             f = getattr(lib, prefix + name + "_dev")
             f.argtypes, f.restype = sig[name] + [vp], ci
+        lib.lbmpc_mc_counters.argtypes, lib.lbmpc_mc_counters.restype = [vp, C.POINTER(C.c_uint64)], ci
         lib.lbmpc_version.restype = ci
         lib.lbmpc_init.argtypes, lib.lbmpc_init.restype = [ci], ci
         lib.lbmpc_last_error.restype = C.c_char_p

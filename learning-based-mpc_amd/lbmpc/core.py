@@ -158,6 +158,13 @@ class Context:
             o = {k: (v[0] if isinstance(v, np.ndarray) else v) for k, v in o.items()}
         return o
 
+    def mc_counters(self):
+        """Work counters of the last Monte-Carlo launch (lbmpc_mc_counters)."""
+        buf = (C.c_uint64 * 8)()
+        _chk(self.lib.lbmpc_mc_counters(self.handle, buf), "lbmpc_mc_counters")
+        names = ["filter_wave_steps", "wave_steps", "qp_solves", "solver_rounds", "solver_trips", "pivot_scans"]
+        return {n: int(buf[i]) for i, n in enumerate(names)}
+
     def mc_run(self, sampler, trials, steps, card_I0, seed, x0, acc_bound, distance_error, trial0=0, traj_trials=0,
                sampler_max_attempts=1000, vol_W=0.0):
         """Batched closed-loop Monte-Carlo (Case_3/4/5 loops); returns host arrays."""
