@@ -441,7 +441,8 @@ struct McArgs {
 // (seed, trial, step, attempt) only, not on the closed-loop state, so they are produced ahead of the closed loop:
 // here every lane walks its own (step, attempt) sequence and no lane waits for another lane's rejections (inside
 // the lock-step closed loop a wave pays the maximum attempt count of its 64 lanes at every step).
-// grid.y = 0: xi_LV, 1: xi_EV.  Same streams and arithmetic as sample_polytope.
+// grid.y = 0: xi_LV, 1: xi_EV; grid.z splits the steps into equal segments (more waves in flight).  Same streams and
+// arithmetic as sample_polytope.
 template <int NX>
 __global__ __launch_bounds__(256) void mc_sample_kernel(SamplerDev smp, int64_t chunk_n, int64_t trial_first, int K,
                                                         uint64_t seed, int max_attempts, double* __restrict__ xi,
@@ -456,9 +457,11 @@ __global__ __launch_bounds__(256) void mc_sample_kernel(SamplerDev smp, int64_t 
     const double* hi = kind ? smp.EV_hi : smp.LV_hi;
     const int nr = kind ? smp.nEV : smp.nLV;
     const uint32_t purpose = kind ? P_ST_EV : P_ST_LV;
-    int k = valid ? 0 : K, att = 0, st = 0;
-    while (__builtin_amdgcn_ballot_w64(k < K) != 0) {
-        if (k < K) {
+    const int seg = (K + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int kend = ((int)blockIdx.z + 1) * seg < K ? ((int)blockIdx.z + 1) * seg : K;
+    int k = valid ? (int)blockIdx.z * seg : kend, att = 0, st = 0;
+    while (__builtin_amdgcn_ballot_w64(k < kend) != 0) {
+        if (k < kend) {
             double u[NX + (NX & 1)], xt[NX];
             draw_uniforms<NX>(seed, tid, (uint32_t)k, purpose, (uint32_t)att, u);
 #pragma unroll
@@ -990,7 +993,12 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
         a.chunk0 = c0; a.chunk_n = cn;
         if (cfg->steps > 0) {
             LB_HIP(hipMemsetAsync(c->xi_status, 0, (size_t)cn * sizeof(int), st));
-            dim3 sg((unsigned)((cn + 255) / 256), 2), sb(256);
+            // enough segments to put about 8 waves on every SIMD
+            const int64_t sblocks = (cn + 255) / 256;
+            int segs = (int)((8192 + sblocks * 8 - 1) / (sblocks * 8));
+            segs = segs < 1 ? 1 : (segs > 8 ? 8 : segs);
+            if (segs > cfg->steps) segs = cfg->steps;
+            dim3 sg((unsigned)sblocks, 2, (unsigned)segs), sb(256);
             switch (c->h.nx) {
                 case 1: hipLaunchKernelGGL((mc_sample_kernel<1>), sg, sb, 0, st, sd, cn, cfg->trial0 + c0, cfg->steps, cfg->seed, cfg->sampler_max_attempts, c->xi, c->xi_status); break;
                 case 2: hipLaunchKernelGGL((mc_sample_kernel<2>), sg, sb, 0, st, sd, cn, cfg->trial0 + c0, cfg->steps, cfg->seed, cfg->sampler_max_attempts, c->xi, c->xi_status); break;

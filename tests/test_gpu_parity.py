@@ -310,3 +310,38 @@ def test_mc_wide_path_matches_narrow(core, P, smp):
     for k in ("infeasible", "status", "qp_iters", "alpha_final", "v_final", "x_final"):
         np.testing.assert_array_equal(wide[k], narrow[k], err_msg=k)
     ctx.close()
+
+
+@pytest.mark.parametrize("system,x0,steps", [("3x3", [-12.0, 5.0, 0.0], 30), ("4x4", [-12.0, 5.0, 0.0, 0.0], 40)])
+def test_mc_generated_systems_vs_oracle(core, system, x0, steps):
+    """C3 / C4 systems (build-generated parameters): closed loop through the transient (filter scans + QP solves)
+    and into the steady state (ellipsoid early-out), whole trajectories vs oracle"""
+    from lbmpc import params
+    Pg = params.load(system)
+    smpg = params.sampler(Pg)
+    ctx, octx = core.Context(Pg), oracle_core.Context(Pg)
+    kw = dict(trials=200, steps=steps, card_I0=10, seed=4, x0=x0, acc_bound=float(Pg["acc_bound"][0]),
+              distance_error=float(Pg["distance_error"][0]), traj_trials=200)
+    g, o = ctx.mc_run(smpg, **kw), octx.mc_run(smpg, **kw)
+    compare_mc(g, o)
+    assert o["qp_iters"].min() > 0
+    cnt = ctx.mc_counters()
+    assert cnt["wave_steps"] == 4 * steps and cnt["qp_solves"] > 0 and cnt["pivot_scans"] >= cnt["solver_rounds"] > 0
+    assert 0 < cnt["filter_wave_steps"] < cnt["wave_steps"]   # transient scanned, steady state skipped
+    ctx.close(); octx.close()
+
+
+def test_mc_trial_chunks_match_single_launch(core, P, smp):
+    """a small disturbance-scratch cap (LBMPC_MC_XI_GIB) splits the run into trial chunks; results are bitwise equal"""
+    import os
+    ctx = core.Context(P)
+    kw = dict(trials=1500, steps=10, card_I0=10, seed=7, x0=[-12.0, 5.0], acc_bound=2.0, distance_error=15.0, traj_trials=1500)
+    one = ctx.mc_run(smp, **kw)
+    try:
+        os.environ["LBMPC_MC_XI_GIB"] = "0.0001"   # ~105 kB -> 512-trial chunks
+        many = ctx.mc_run(smp, **kw)
+    finally:
+        os.environ.pop("LBMPC_MC_XI_GIB", None)
+    for k in one:
+        np.testing.assert_array_equal(one[k], many[k], err_msg=k)
+    ctx.close()
