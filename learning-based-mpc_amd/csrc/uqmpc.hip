@@ -430,11 +430,24 @@ struct McArgs {
     int traj_trials, sampler_max_attempts;
     // this launch covers local trials [chunk0, chunk0 + chunk_n); xi holds their pre-drawn step disturbances
     int64_t chunk0, chunk_n;
-    const double* xi;       // [step][chunk trial][LV nx | EV nx]
+    const double* xi;       // pre-drawn xi_LV / xi_EV, layout xi_index()
     const int* xi_status;   // [chunk trial] LBMPC_ST_SAMPLER_CAP if a step sampler hit the attempt cap
     unsigned long long* counters;  // 8 work counters of this launch
     lbmpc_mc_out out;
 };
+
+// Layout of the pre-drawn disturbances: [kind][64-trial group][group of 4 steps][lane][step in group][nx].  A lane's
+// four consecutive steps are one contiguous run (written at once by the pre-pass: a full 128-byte line at nx = 4), and
+// the runs of the 64 lanes of a wave are adjacent, so a closed-loop step reads one contiguous 64-run window per kind
+// and re-reads the same lines for the next three steps.
+template <int NX>
+__host__ __device__ inline int64_t xi_index(int kind, int64_t cl, int k, int K, int64_t chunk_n) {
+    const int64_t nW = (chunk_n + 63) >> 6, KG = (K + 3) >> 2;
+    return (((((int64_t)kind * nW + (cl >> 6)) * KG + (k >> 2)) * 64 + (cl & 63)) * 4 + (k & 3)) * NX;
+}
+__host__ inline size_t xi_bytes_for(int nx, int K, int64_t chunk_n) {
+    return (size_t)2 * (size_t)((chunk_n + 63) >> 6) * (size_t)((K + 3) >> 2) * 64 * 4 * nx * 8;
+}
 
 // ---- step-disturbance pre-pass ------------------------------------------------------------------------
 // xi_LV / xi_EV of every (trial, step) by rejection sampling (ModelingCar.m:36-43 via :47-91).  The draws depend on
@@ -457,9 +470,13 @@ __global__ __launch_bounds__(256) void mc_sample_kernel(SamplerDev smp, int64_t 
     const double* hi = kind ? smp.EV_hi : smp.LV_hi;
     const int nr = kind ? smp.nEV : smp.nLV;
     const uint32_t purpose = kind ? P_ST_EV : P_ST_LV;
-    const int seg = (K + (int)gridDim.z - 1) / (int)gridDim.z;
-    const int kend = ((int)blockIdx.z + 1) * seg < K ? ((int)blockIdx.z + 1) * seg : K;
-    int k = valid ? (int)blockIdx.z * seg : kend, att = 0, st = 0;
+    const int seg = (((K + (int)gridDim.z - 1) / (int)gridDim.z) + 3) & ~3;  // whole groups of 4 steps
+    const int kbeg = (int)blockIdx.z * seg < K ? (int)blockIdx.z * seg : K;
+    const int kend = kbeg + seg < K ? kbeg + seg : K;
+    // accepted draws are collected four steps at a time and leave as one 4*NX*8-byte run (xi_index; a full line at
+    // nx = 4): scattered 32-byte stores of single draws cost as much as the sampling itself
+    double buf[4][NX];
+    int k = valid ? kbeg : kend, att = 0, st = 0;
     while (__builtin_amdgcn_ballot_w64(k < kend) != 0) {
         if (k < kend) {
             double u[NX + (NX & 1)], xt[NX];
@@ -475,11 +492,25 @@ __global__ __launch_bounds__(256) void mc_sample_kernel(SamplerDev smp, int64_t 
             }
             const bool last = att + 1 >= max_attempts;
             if (ok || last) {
-                double* dst = xi + (((int64_t)k * chunk_n + cl) * 2 + kind) * NX;
+                const int slot = (k - kbeg) & 3;
 #pragma unroll
-                for (int i = 0; i < NX; ++i) dst[i] = xt[i];
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) buf[j][i] = slot == j ? xt[i] : buf[j][i];
                 if (!ok) st = LBMPC_ST_SAMPLER_CAP;
                 ++k; att = 0;
+                if (slot == 3 || k == kend) {
+                    double* dst = xi + xi_index<NX>(kind, valid ? cl : 0, k - 1 - slot, K, chunk_n);  // kbeg % 4 == 0
+#ifdef LBMPC_ABLATE_XI_STORE
+                    if (k == kend)
+#endif
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (j <= slot) {
+#pragma unroll
+                            for (int i = 0; i < NX; ++i) dst[j * NX + i] = buf[j][i];
+                        }
+                }
             } else {
                 ++att;
             }
@@ -559,17 +590,19 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
         }
         for (int k = 0; k < K; ++k) {
             double q[T][NX], xi_lv[T][NX], xi_ev[T][NX], Bul[T][NX], momh[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const double* xl = a.xi + xi_index<NX>(0, cl[t], k, K, a.chunk_n);
+                const double* xe = a.xi + xi_index<NX>(1, cl[t], k, K, a.chunk_n);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { xi_lv[t][i] = xl[i]; xi_ev[t][i] = xe[i]; }
+            }
             int aomh[T];
             bool need[T];
             PROF_T(p0);
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 // LVModeling first (Case_3...:58; ModelingCar.m:42-43): xi_LV, xi_EV come from the pre-pass
-                {
-                    const double* xp = a.xi + (((int64_t)k * a.chunk_n + cl[t]) * 2) * NX;
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) { xi_lv[t][i] = xp[i]; xi_ev[t][i] = xp[NX + i]; }
-                }
                 sample_Bu_lv<NX>(S, a.seed, tid[t], (uint32_t)k, P_ST_U, Bul[t]);
                 double bh[2 * NX];
                 int st = uq_update<NX>(C, alpha[t], v[t], wst[t], bh);  // w_new = 0 at k = 0 (Case_3...:62-65)
@@ -960,7 +993,7 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
     const size_t lds = c->lds_const_bytes + (size_t)waves * ws_doubles(c->h.nz) * 8;
     const int per_block = waves * 64 * (wide ? 2 : 1);
     // trial chunks: the pre-drawn disturbances of one chunk take steps * 2 nx * 8 B per trial
-    const size_t per_trial = (size_t)cfg->steps * 2 * c->h.nx * 8;
+    const size_t per_trial = xi_bytes_for(c->h.nx, cfg->steps, 64) / 64;
     const char* env_g = getenv("LBMPC_MC_XI_GIB");
     const double cap_gib = env_g ? atof(env_g) : 16.0;
     int64_t chunk = cfg->trials;
@@ -970,7 +1003,7 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
     }
     if (chunk > cfg->trials) chunk = cfg->trials;
     {
-        const size_t need = (size_t)chunk * per_trial;
+        const size_t need = xi_bytes_for(c->h.nx, cfg->steps, chunk);
         if (need > c->xi_bytes) {
             if (c->xi) LB_HIP(hipFree(c->xi));
             c->xi = nullptr; c->xi_bytes = 0;
