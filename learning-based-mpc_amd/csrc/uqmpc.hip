@@ -436,17 +436,16 @@ struct McArgs {
     lbmpc_mc_out out;
 };
 
-// Layout of the pre-drawn disturbances: [kind][64-trial group][group of 4 steps][lane][step in group][nx].  A lane's
-// four consecutive steps are one contiguous run (written at once by the pre-pass: a full 128-byte line at nx = 4), and
-// the runs of the 64 lanes of a wave are adjacent, so a closed-loop step reads one contiguous 64-run window per kind
-// and re-reads the same lines for the next three steps.
+// Layout of the pre-drawn disturbances: [kind][step][chunk trial][nx] with chunk trials padded to a multiple of 4;
+// kind 0 holds xi_LV + B u_LV (the sum the plant update subtracts), kind 1 holds xi_EV.  A closed-loop step reads
+// one contiguous 64*nx*8-byte window per kind and wave; the pre-pass writes it in full lines (4 trials per thread).
 template <int NX>
 __host__ __device__ inline int64_t xi_index(int kind, int64_t cl, int k, int K, int64_t chunk_n) {
-    const int64_t nW = (chunk_n + 63) >> 6, KG = (K + 3) >> 2;
-    return (((((int64_t)kind * nW + (cl >> 6)) * KG + (k >> 2)) * 64 + (cl & 63)) * 4 + (k & 3)) * NX;
+    const int64_t np = (chunk_n + 3) & ~(int64_t)3;
+    return (((int64_t)kind * K + k) * np + cl) * NX;
 }
 __host__ inline size_t xi_bytes_for(int nx, int K, int64_t chunk_n) {
-    return (size_t)2 * (size_t)((chunk_n + 63) >> 6) * (size_t)((K + 3) >> 2) * 64 * 4 * nx * 8;
+    return (size_t)2 * (size_t)K * (size_t)((chunk_n + 3) & ~(int64_t)3) * nx * 8;
 }
 
 // ---- step-disturbance pre-pass ------------------------------------------------------------------------
@@ -454,31 +453,34 @@ __host__ inline size_t xi_bytes_for(int nx, int K, int64_t chunk_n) {
 // (seed, trial, step, attempt) only, not on the closed-loop state, so they are produced ahead of the closed loop:
 // here every lane walks its own (step, attempt) sequence and no lane waits for another lane's rejections (inside
 // the lock-step closed loop a wave pays the maximum attempt count of its 64 lanes at every step).
-// grid.y = 0: xi_LV, 1: xi_EV; grid.z splits the steps into equal segments (more waves in flight).  Same streams and
-// arithmetic as sample_polytope.
+// grid.y = 0: xi_LV (+ B u_LV, ModelingCar.m:42-43), 1: xi_EV; grid.z splits the steps into equal segments (more waves
+// in flight).  Every thread serves FOUR adjacent trials, step by step, so that the four accepted draws of a step leave
+// as one contiguous 4*nx*8-byte run of the step-major layout (a full 128-byte line at nx = 4): single 32-byte stores
+// cost as much as the sampling itself.  Same streams and arithmetic as sample_polytope / sample_Bu_lv.
 template <int NX>
 __global__ __launch_bounds__(256) void mc_sample_kernel(SamplerDev smp, int64_t chunk_n, int64_t trial_first, int K,
                                                         uint64_t seed, int max_attempts, double* __restrict__ xi,
                                                         int* __restrict__ xi_status) {
     const int kind = blockIdx.y;
-    const int64_t cl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = cl < chunk_n;
-    const uint64_t tid = (uint64_t)(trial_first + (valid ? cl : chunk_n - 1));
+    const int64_t g4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // trials 4 g4 .. 4 g4 + 3 of the chunk
+    const int64_t ngroups = (chunk_n + 3) >> 2;
+    const bool valid = g4 < ngroups;
+    const int64_t cl0 = valid ? 4 * g4 : 0;
     const double* XA = kind ? smp.EV_A : smp.LV_A;
     const double* Xb = kind ? smp.EV_b : smp.LV_b;
     const double* lo = kind ? smp.EV_lo : smp.LV_lo;
     const double* hi = kind ? smp.EV_hi : smp.LV_hi;
     const int nr = kind ? smp.nEV : smp.nLV;
     const uint32_t purpose = kind ? P_ST_EV : P_ST_LV;
-    const int seg = (((K + (int)gridDim.z - 1) / (int)gridDim.z) + 3) & ~3;  // whole groups of 4 steps
+    const int seg = (K + (int)gridDim.z - 1) / (int)gridDim.z;
     const int kbeg = (int)blockIdx.z * seg < K ? (int)blockIdx.z * seg : K;
     const int kend = kbeg + seg < K ? kbeg + seg : K;
-    // accepted draws are collected four steps at a time and leave as one 4*NX*8-byte run (xi_index; a full line at
-    // nx = 4): scattered 32-byte stores of single draws cost as much as the sampling itself
     double buf[4][NX];
-    int k = valid ? kbeg : kend, att = 0, st = 0;
+    int k = valid ? kbeg : kend, j = 0, att = 0, st = 0;  // task = (step k, trial cl0 + j)
     while (__builtin_amdgcn_ballot_w64(k < kend) != 0) {
         if (k < kend) {
+            const int64_t clj = cl0 + j < chunk_n ? cl0 + j : chunk_n - 1;  // padding trials repeat the last one
+            const uint64_t tid = (uint64_t)(trial_first + clj);
             double u[NX + (NX & 1)], xt[NX];
             draw_uniforms<NX>(seed, tid, (uint32_t)k, purpose, (uint32_t)att, u);
 #pragma unroll
@@ -492,35 +494,41 @@ __global__ __launch_bounds__(256) void mc_sample_kernel(SamplerDev smp, int64_t 
             }
             const bool last = att + 1 >= max_attempts;
             if (ok || last) {
-                const int slot = (k - kbeg) & 3;
+                if (kind == 0) {  // the plant update subtracts (xi_LV + B u_LV): form that sum here
+                    double Bul[NX];
+                    sample_Bu_lv<NX>(&smp, seed, tid, (uint32_t)k, P_ST_U, Bul);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                    for (int i = 0; i < NX; ++i) xt[i] = xt[i] + Bul[i];
+                }
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) buf[j][i] = slot == j ? xt[i] : buf[j][i];
-                if (!ok) st = LBMPC_ST_SAMPLER_CAP;
-                ++k; att = 0;
-                if (slot == 3 || k == kend) {
-                    double* dst = xi + xi_index<NX>(kind, valid ? cl : 0, k - 1 - slot, K, chunk_n);  // kbeg % 4 == 0
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) buf[jj][i] = j == jj ? xt[i] : buf[jj][i];
+                if (!ok && cl0 + j < chunk_n) atomicMax(&xi_status[cl0 + j], (int)LBMPC_ST_SAMPLER_CAP);
+                att = 0;
+                if (j == 3) {
+                    double* dst = xi + xi_index<NX>(kind, cl0, k, K, chunk_n);
 #ifdef LBMPC_ABLATE_XI_STORE
-                    if (k == kend)
+                    if (k == kend - 1)
 #endif
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (j <= slot) {
+                    for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                            for (int i = 0; i < NX; ++i) dst[j * NX + i] = buf[j][i];
-                        }
+                        for (int i = 0; i < NX; ++i) dst[jj * NX + i] = buf[jj][i];
+                    j = 0; ++k;
+                } else {
+                    ++j;
                 }
             } else {
                 ++att;
             }
         }
     }
-    if (valid && st) atomicMax(&xi_status[cl], st);
+    (void)st;
 }
 
 #ifdef LBMPC_PROFILE
-__device__ unsigned long long lbmpc_prof[16];
+__device__ unsigned long long lbmpc_prof[24];
 #define PROF_T(var) const long long var = clock64()
 #define PROF_ADD(slot, t0, t1) prof[slot] += (t1) - (t0)
 #define PROF_PTR (prof + 8)
@@ -541,7 +549,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
     const SamplerDev* S = &smp;
     unsigned ctr[6] = {0, 0, 0, 0, 0, 0};  // wave-uniform work counters (lbmpc_mc_counters)
 #ifdef LBMPC_PROFILE
-    long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long prof[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     PROF_T(pk0);
 #endif
     for (int64_t base = ((int64_t)blockIdx.x * nwaves + wave) * (LB_WAVE * T); base < a.chunk_n;
@@ -589,7 +597,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
             }
         }
         for (int k = 0; k < K; ++k) {
-            double q[T][NX], xi_lv[T][NX], xi_ev[T][NX], Bul[T][NX], momh[T];
+            double q[T][NX], xi_lv[T][NX], xi_ev[T][NX], momh[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 const double* xl = a.xi + xi_index<NX>(0, cl[t], k, K, a.chunk_n);
@@ -603,11 +611,14 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 // LVModeling first (Case_3...:58; ModelingCar.m:42-43): xi_LV, xi_EV come from the pre-pass
-                sample_Bu_lv<NX>(S, a.seed, tid[t], (uint32_t)k, P_ST_U, Bul[t]);
+                PROF_T(pa);
                 double bh[2 * NX];
                 int st = uq_update<NX>(C, alpha[t], v[t], wst[t], bh);  // w_new = 0 at k = 0 (Case_3...:62-65)
                 status[t] = st > status[t] ? st : status[t];
+                PROF_T(pb);
                 tighten<NX>(C, alpha[t], v[t], x[t], q[t], momh[t], aomh[t]);
+                PROF_T(pc);
+                PROF_ADD(16, p0, pa); PROF_ADD(17, pa, pb); PROF_ADD(18, pb, pc);
             }
             PROF_T(p1);
             ctr[0] += first_pass<NX, T>(C, L, alpha, q, momh, need) ? T : 0;
@@ -626,8 +637,9 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
                 prof[4] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid[t] && need[t]));
                 prof[5] += (__builtin_popcountll(__builtin_amdgcn_ballot_w64(valid[t] && need[t])) + 3) >> 2;
 #endif
-                solve_flagged<NX>(C, L, ws, valid[t] && need[t], alpha[t], v[t], q[t], s0, c0,
-                                  status[t], iters[t], nullptr, nullptr, nullptr, ctr + 2, PROF_PTR);
+                if (__builtin_amdgcn_ballot_w64(valid[t] && need[t]) != 0)  // keeps the solver's spill code off the steady-state path
+                    solve_flagged<NX>(C, L, ws, valid[t] && need[t], alpha[t], v[t], q[t], s0, c0,
+                                      status[t], iters[t], nullptr, nullptr, nullptr, ctr + 2, PROF_PTR);
                 PROF_T(p4);
                 PROF_ADD(2, p3, p4);
                 // u = K x + c(1:nu); EVModeling (ModelingCar.m:36-37); relative dynamics
@@ -651,7 +663,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
 #pragma unroll
                     for (int j = 0; j < LBMPC_MAX_NU; ++j) if (j < nu) bcc = fma(C->B[i * nu + j], u[j], bcc);
                     Ax[i] = acc; Bu[i] = bcc;
-                    xn[i] = ((Ax[i] + Bu[i]) + xi_ev[t][i]) - (xi_lv[t][i] + Bul[t][i]);
+                    xn[i] = ((Ax[i] + Bu[i]) + xi_ev[t][i]) - xi_lv[t][i];  // xi_lv holds xi_LV + B u_LV
                 }
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
@@ -691,12 +703,12 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
 #ifdef LBMPC_PROFILE
     PROF_T(pk1);
     prof[6] = pk1 - pk0;
-    if (lane == 0) for (int i = 0; i < 16; ++i) atomicAdd(&lbmpc_prof[i], (unsigned long long)prof[i]);
+    if (lane == 0) for (int i = 0; i < 24; ++i) atomicAdd(&lbmpc_prof[i], (unsigned long long)prof[i]);
 #endif
 }
 #ifdef LBMPC_PROFILE
 extern "C" int lbmpc_prof_read(unsigned long long* out, int reset) {
-    unsigned long long z[16] = {0};
+    unsigned long long z[24] = {0};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(lbmpc_prof), sizeof(z)) != hipSuccess) return -1;
     if (reset && hipMemcpyToSymbol(HIP_SYMBOL(lbmpc_prof), z, sizeof(z)) != hipSuccess) return -1;
     return 0;
@@ -1027,9 +1039,9 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
         if (cfg->steps > 0) {
             LB_HIP(hipMemsetAsync(c->xi_status, 0, (size_t)cn * sizeof(int), st));
             // enough segments to put about 8 waves on every SIMD
-            const int64_t sblocks = (cn + 255) / 256;
+            const int64_t sblocks = ((cn + 3) / 4 + 255) / 256;
             int segs = (int)((8192 + sblocks * 8 - 1) / (sblocks * 8));
-            segs = segs < 1 ? 1 : (segs > 8 ? 8 : segs);
+            segs = segs < 1 ? 1 : (segs > 64 ? 64 : segs);
             if (segs > cfg->steps) segs = cfg->steps;
             dim3 sg((unsigned)sblocks, 2, (unsigned)segs), sb(256);
             switch (c->h.nx) {

@@ -9,7 +9,7 @@ ctx = core.Context(P)
 smp = params.sampler(P)
 trials = int(os.environ.get("TRIALS", 131072)); K = int(os.environ.get("K", 1000))
 lib = _abi.load()
-buf = (ctypes.c_ulonglong * 16)()
+buf = (ctypes.c_ulonglong * 24)()
 lib.lbmpc_prof_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
 for rep in range(2):
     lib.lbmpc_prof_read(buf, 1)
@@ -32,3 +32,5 @@ print("  solver: scan %.1f%%  step2 %.1f%%  add %.1f%%  drop %.1f%% of solve; lo
     g[0] / v[2] * 100, g[1] / v[2] * 100, g[2] / v[2] * 100, g[3] / v[2] * 100, g[4], g[5], g[6]))
 if g[4] > 0:
     print("  cycles: per scan %.0f  per step2 %.0f  per add %.0f  per drop-phase %.0f" % (g[0] / max(g[5], 1), g[1] / g[4], g[2] / g[4], g[3] / max(g[6], 1)))
+print("  per wave-step ticks: Bu_lv %.0f  uq_update %.0f  tighten %.0f  first_pass %.0f  ev+dyn %.0f" % tuple(
+    v[i] / (trials / 64 * K) for i in (16, 17, 18, 1, 3)))
