@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--sl-sets", type=int, default=8192, help="information sets per GPU in the set-learning leg")
     ap.add_argument("--sl-n", type=int, default=20000, help="samples per information set")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-trials", type=int, default=512)
+    ap.add_argument("--cpu-trials", type=int, default=2048)
     args = ap.parse_args()
 
     from lbmpc import core, dev, dist as ldist, params
@@ -166,6 +166,18 @@ def main():
                "sample": f"{ct} trials x {args.horizon} steps of the same {args.system} workload (trial ids 0..{ct - 1}), "
                          f"oracle/lbmpc_oracle.c single thread, {cdt:.1f} s; parity of these trials checked against the GPU run",
                "reference_stored_matlab_steps_per_s": 15.4}
+    # HBM traffic per launch from the committed PMC pass (tools/profile_round.sh), valid for the default sizes only
+    traffic_mc = traffic_sl = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+            pk = json.load(f)["kernels"]
+        if (B, N) == (8192, 20000):
+            k2 = next(v for k, v in pk.items() if "halfspace_max_kernel" in k)
+            traffic_sl = k2.get("hbm_read_bytes", 0.0) + k2.get("hbm_write_bytes", 0.0)
+        if (args.trials, args.horizon, args.system) == (131072, 1000, "4x4"):
+            traffic_mc = sum(v.get("hbm_read_bytes", 0.0) + v.get("hbm_write_bytes", 0.0) for k, v in pk.items() if "mc_" in k)
+    except (OSError, KeyError, StopIteration, ValueError):
+        pass
     if rank == 0:
         out = {
             "metric": "closed-loop MPC steps/sec (batched MC trials, 4x4) + samples/sec set learning",
@@ -177,7 +189,7 @@ def main():
                        "trials_per_gpu": args.trials, "horizon": args.horizon, "nS": int(nS), "nH": int(nH), "nz": int(nz),
                        "parallelism": f"trial-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": None, "kernel": "mc_kernel (+ mc_sample_kernel pre-pass)",
+                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic_mc, "kernel": "mc_kernel (+ mc_sample_kernel pre-pass)",
                          "kernel_ms": kern_ms, "algorithmic_flops_per_launch": flops, "executed": executed,
                          "note": "MFMA deliberately unused (north_star); bound is the fp64 vector rate. achieved prices the "
                                  "algorithmic flops (one S pass per step + one full pass per active-set iteration); the kernels "
@@ -186,7 +198,7 @@ def main():
             "set_learning": {"value": sl_value, "unit": "samples/s", "ms_per_step": sl_ms,
                              "config": {"workload": f"C2: 2x2 set learning, {B} information sets/GPU x {N} samples resident in HBM"},
                              "roofline": {"bound": "hbm", "achieved": sl_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                          "frac": sl_gbs / HBM_PEAK_GBS, "traffic": None, "kernel": "halfspace_max_kernel",
+                                          "frac": sl_gbs / HBM_PEAK_GBS, "traffic": traffic_sl, "kernel": "halfspace_max_kernel",
                                           "algorithmic_bytes_per_launch": sl_bytes}},
             "mc_stats": {"infeasible_trials": int(infeas.sum().item()), "max_status": int(status.max().item()),
                          "mean_qp_iters_per_trial": float(iters.double().mean().item())},

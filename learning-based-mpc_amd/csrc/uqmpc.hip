@@ -67,6 +67,8 @@ struct lbmpc_ctx {
     int* xi_status = nullptr;
     size_t xi_status_n = 0;
     unsigned long long* counters = nullptr;  // 8 work counters of the last mc_run
+    double* park = nullptr;                  // state parked during solves, PARK_SLOTS doubles per grid thread
+    size_t park_bytes = 0;
 };
 
 namespace lbmpc {
@@ -433,6 +435,7 @@ struct McArgs {
     const double* xi;       // pre-drawn xi_LV / xi_EV, layout xi_index()
     const int* xi_status;   // [chunk trial] LBMPC_ST_SAMPLER_CAP if a step sampler hit the attempt cap
     unsigned long long* counters;  // 8 work counters of this launch
+    double* park;           // [slot][thread of the grid]: closed-loop state parked during a solve (mc_kernel)
     lbmpc_mc_out out;
 };
 
@@ -637,9 +640,47 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
                 prof[4] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid[t] && need[t]));
                 prof[5] += (__builtin_popcountll(__builtin_amdgcn_ballot_w64(valid[t] && need[t])) + 3) >> 2;
 #endif
-                if (__builtin_amdgcn_ballot_w64(valid[t] && need[t]) != 0)  // keeps the solver's spill code off the steady-state path
-                    solve_flagged<NX>(C, L, ws, valid[t] && need[t], alpha[t], v[t], q[t], s0, c0,
+                if (__builtin_amdgcn_ballot_w64(valid[t] && need[t]) != 0) {
+                    // Entered in ~1 % of the steps of a long horizon.  The closed-loop state is parked in HBM for
+                    // the duration of the solve (and read back through a laundered pointer, so that the values are
+                    // new ones): otherwise the solver's register peak makes the allocator spill that state on the
+                    // steady-state path of EVERY step (14.7 GB of scratch writes per C4 launch before this).
+                    double* pk = a.park + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+                    const int64_t ps = (int64_t)gridDim.x * blockDim.x;
+                    int slot = 0;
+#pragma unroll
+                    for (int tt = 0; tt < T; ++tt) {
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) {
+                            pk[(slot++) * ps] = x[tt][i]; pk[(slot++) * ps] = v[tt][i];
+                            pk[(slot++) * ps] = xi_lv[tt][i]; pk[(slot++) * ps] = xi_ev[tt][i];
+                        }
+                        pk[(slot++) * ps] = alpha[tt];
+                        pk[(slot++) * ps] = __longlong_as_double(tl[tt]);
+                        pk[(slot++) * ps] = __longlong_as_double(cl[tt]);
+                        pk[(slot++) * ps] = __longlong_as_double((long long)tid[tt]);
+                    }
+                    const double a_t = alpha[t];
+                    double v_t[NX], q_t[NX];
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) { v_t[i] = v[t][i]; q_t[i] = q[t][i]; }
+                    solve_flagged<NX>(C, L, ws, valid[t] && need[t], a_t, v_t, q_t, s0, c0,
                                       status[t], iters[t], nullptr, nullptr, nullptr, ctr + 2, PROF_PTR);
+                    asm volatile("" : "+v"(pk));
+                    slot = 0;
+#pragma unroll
+                    for (int tt = 0; tt < T; ++tt) {
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) {
+                            x[tt][i] = pk[(slot++) * ps]; v[tt][i] = pk[(slot++) * ps];
+                            xi_lv[tt][i] = pk[(slot++) * ps]; xi_ev[tt][i] = pk[(slot++) * ps];
+                        }
+                        alpha[tt] = pk[(slot++) * ps];
+                        tl[tt] = __double_as_longlong(pk[(slot++) * ps]);
+                        cl[tt] = __double_as_longlong(pk[(slot++) * ps]);
+                        tid[tt] = (uint64_t)__double_as_longlong(pk[(slot++) * ps]);
+                    }
+                }
                 PROF_T(p4);
                 PROF_ADD(2, p3, p4);
                 // u = K x + c(1:nu); EVModeling (ModelingCar.m:36-37); relative dynamics
@@ -803,6 +844,7 @@ extern "C" void lbmpc_destroy(lbmpc_ctx* c) {
     if (c->xi) (void)hipFree(c->xi);
     if (c->xi_status) (void)hipFree(c->xi_status);
     if (c->counters) (void)hipFree(c->counters);
+    if (c->park) (void)hipFree(c->park);
     delete c;
 }
 
@@ -1056,6 +1098,16 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
         const int64_t resident = 256 * (int64_t)(LDS_LIMIT / lds > 4 ? 4 : (LDS_LIMIT / lds < 1 ? 1 : LDS_LIMIT / lds));
         if (blocks > resident * 4) blocks = resident * 4;
         dim3 grid((unsigned)blocks), blk(waves * 64);
+        {
+            const size_t need = (size_t)blocks * waves * 64 * 2 * (4 * LBMPC_MAX_NX + 4) * 8;  // T <= 2
+            if (need > c->park_bytes) {
+                if (c->park) LB_HIP(hipFree(c->park));
+                c->park = nullptr; c->park_bytes = 0;
+                LB_HIP(hipMalloc((void**)&c->park, need));
+                c->park_bytes = need;
+            }
+            a.park = c->park;
+        }
 #define LAUNCH_MC(NXV, TV)                                                                      \
     do {                                                                                        \
         if (int rc = allow_lds(mc_kernel<NXV, TV>, lds)) return rc;                             \
