@@ -165,7 +165,7 @@ __device__ __forceinline__ void scan_rows(const CtxDev* __restrict__ C, const Ld
 #pragma unroll
             for (int gg = 0; gg < 2; ++gg)
 #pragma unroll
-                for (int k = 0; k < NZMAX; ++k) zu[gg][k] = (k < 4 * nz4) ? readlane_f64(my_z, 16 * (g0 + gg) + k) : 0.0;
+                for (int k = 0; k < NZMAX; ++k) zu[gg][k] = readlane_f64(my_z, 16 * (g0 + gg) + k);  // lanes >= nz hold 0
             int r = lane % nc;
             const int rstep = 64 % nc;
             const double* hb = L.Hm;
@@ -241,13 +241,23 @@ __device__ __forceinline__ void chol_append_row(const CtxDev* __restrict__ C, co
         acc = (k < len) ? fma(cr[k], gk, acc) : acc;
     });
     acc = (pred && i <= a) ? acc : 0.0;
+    int amax;  // largest row index being appended among the four rows (wave-uniform)
+    {
+        const int ap = pred ? a : 0;
+        const int n0 = __builtin_amdgcn_readlane(ap, 0), n1 = __builtin_amdgcn_readlane(ap, 16);
+        const int n2 = __builtin_amdgcn_readlane(ap, 32), n3 = __builtin_amdgcn_readlane(ap, 48);
+        const int n01 = n0 > n1 ? n0 : n1, n23 = n2 > n3 ? n2 : n3;
+        amax = n01 > n23 ? n01 : n23;
+    }
     static_for<0, NZMAX>([&](auto K) {
         constexpr int k = K;
-        const double yk = rowb<k>(acc) * rowb<k>(my_invd);
-        if (k < a) {
-            if (i == k) acc = yk;
-            else if (i > k && i < a) acc = fma(-yk, LL[k], acc);
-            else if (i == a) acc = fma(-yk, yk, acc);
+        if (k < amax) {
+            const double yk = rowb<k>(acc) * rowb<k>(my_invd);
+            if (k < a) {
+                if (i == k) acc = yk;
+                else if (i > k && i < a) acc = fma(-yk, LL[k], acc);
+                else if (i == a) acc = fma(-yk, yk, acc);
+            }
         }
     });
     if (pred && i == a) {
@@ -257,10 +267,12 @@ __device__ __forceinline__ void chol_append_row(const CtxDev* __restrict__ C, co
     // store: lane b < a keeps L[a][b] as its column entry a; lane a gathers its row
     static_for<0, NZMAX>([&](auto K) {
         constexpr int k = K;
-        const double lab = rowb<k>(acc);  // L[a][k] for k < a
-        if (pred) {
-            if (i < a && k == a) LL[k] = acc;
-            if (i == a && k < a) LL[k] = lab;
+        if (k <= amax) {
+            const double lab = rowb<k>(acc);  // L[a][k] for k < a
+            if (pred) {
+                if (i < a && k == a) LL[k] = acc;
+                if (i == a && k < a) LL[k] = lab;
+            }
         }
     });
 }
@@ -351,31 +363,45 @@ __device__ __forceinline__ void group_qp_solve(const CtxDev* __restrict__ C, con
             });
             my_rhs = (act2 && i < nq) ? my_rhs : 0.0;
         }
+        // largest active-set size among the four rows (wave-uniform): the sweeps stop there
+        int nqmax;
+        {
+            const int n0 = __builtin_amdgcn_readlane(nq, 0), n1 = __builtin_amdgcn_readlane(nq, 16);
+            const int n2 = __builtin_amdgcn_readlane(nq, 32), n3 = __builtin_amdgcn_readlane(nq, 48);
+            const int n01 = n0 > n1 ? n0 : n1, n23 = n2 > n3 ? n2 : n3;
+            nqmax = n01 > n23 ? n01 : n23;
+        }
         double acc = my_rhs;
         static_for<0, NZMAX>([&](auto K) {  // L y = rhs
             constexpr int k = K;
-            const double yk = rowb<k>(acc) * rowb<k>(my_invd);
-            if (k < nq) {
-                if (i == k) acc = yk;
-                else if (i > k && i < nq) acc = fma(-LL[k], yk, acc);
+            if (k < nqmax) {
+                const double yk = rowb<k>(acc) * rowb<k>(my_invd);
+                if (k < nq) {
+                    if (i == k) acc = yk;
+                    else if (i > k && i < nq) acc = fma(-LL[k], yk, acc);
+                }
             }
         });
         static_for_down<NZMAX - 1>([&](auto K) {  // L' r = y
             constexpr int k = K;
-            const double rk = rowb<k>(acc) * rowb<k>(my_invd);
-            if (k < nq) {
-                if (i == k) acc = rk;
-                else if (i < k) acc = fma(-LL[k], rk, acc);
+            if (k < nqmax) {
+                const double rk = rowb<k>(acc) * rowb<k>(my_invd);
+                if (k < nq) {
+                    if (i == k) acc = rk;
+                    else if (i < k) acc = fma(-LL[k], rk, acc);
+                }
             }
         });
         const double my_r = (i < nq) ? acc : 0.0;
         double delta = cg, zacc = my_g;
         static_for<0, NZMAX>([&](auto K) {
             constexpr int a = K;
-            const double ra = rowb<a>(my_r), rh = rowb<a>(my_rhs);
-            if (a < nq) {
-                delta = fma(-rh, ra, delta);
-                zacc = fma(-WmK[a], ra, zacc);
+            if (a < nqmax) {
+                const double ra = rowb<a>(my_r), rh = rowb<a>(my_rhs);
+                if (a < nq) {
+                    delta = fma(-rh, ra, delta);
+                    zacc = fma(-WmK[a], ra, zacc);
+                }
             }
         });
         const double zd = -zacc;  // primal direction, component i: -(g - Wm' r)

@@ -532,6 +532,7 @@ __global__ __launch_bounds__(256) void mc_sample_kernel(SamplerDev smp, int64_t 
 
 #ifdef LBMPC_PROFILE
 __device__ unsigned long long lbmpc_prof[24];
+__device__ unsigned long long lbmpc_prof_wave[3 * 4096];  // per wave: lifetime, solve ticks, rounds
 #define PROF_T(var) const long long var = clock64()
 #define PROF_ADD(slot, t0, t1) prof[slot] += (t1) - (t0)
 #define PROF_PTR (prof + 8)
@@ -600,6 +601,19 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
             }
         }
         for (int k = 0; k < K; ++k) {
+            // The two waves of a SIMD are issue-arbitrated oldest first: left alone, waves 4..7 of the block run
+            // 27 % longer than waves 0..3 through the same work and the kernel ends with them.  Alternating the
+            // priority so that the wave that is behind wins splits the advantage evenly.
+            {
+                // progress of this wave, published in a spare word of its solver slot; partner = the other wave of the SIMD
+                volatile int* prog = reinterpret_cast<volatile int*>(ws_base + 47);
+                const int stride = ws_doubles(nz) * 2;  // ints per wave slot
+                if (lane == 0) prog[wave * stride] = k;
+                const int pw = wave ^ 4;
+                const int pk = pw < nwaves ? prog[pw * stride] : k;
+                const bool ahead = k > pk || (k == pk && ((k ^ (wave >> 2)) & 1) == 0);
+                if (ahead) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2);
+            }
             double q[T][NX], xi_lv[T][NX], xi_ev[T][NX], momh[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
@@ -744,10 +758,18 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
 #ifdef LBMPC_PROFILE
     PROF_T(pk1);
     prof[6] = pk1 - pk0;
-    if (lane == 0) for (int i = 0; i < 24; ++i) atomicAdd(&lbmpc_prof[i], (unsigned long long)prof[i]);
+    if (lane == 0) {
+        for (int i = 0; i < 24; ++i) if (i != 7) atomicAdd(&lbmpc_prof[i], (unsigned long long)prof[i]);
+        atomicMax(&lbmpc_prof[7], (unsigned long long)prof[6]);  // slowest wave
+        const int gw = blockIdx.x * nwaves + wave;
+        if (gw < 4096) { lbmpc_prof_wave[3 * gw] = prof[6]; lbmpc_prof_wave[3 * gw + 1] = prof[2]; lbmpc_prof_wave[3 * gw + 2] = prof[5]; }
+    }
 #endif
 }
 #ifdef LBMPC_PROFILE
+extern "C" int lbmpc_prof_read_waves(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(lbmpc_prof_wave), sizeof(unsigned long long) * 3 * 4096) == hipSuccess ? 0 : -1;
+}
 extern "C" int lbmpc_prof_read(unsigned long long* out, int reset) {
     unsigned long long z[24] = {0};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(lbmpc_prof), sizeof(z)) != hipSuccess) return -1;
