@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--sl-n", type=int, default=20000, help="samples per information set")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-trials", type=int, default=2048)
+    ap.add_argument("--sweep-dirs", type=int, default=1000000)
     args = ap.parse_args()
 
     from lbmpc import core, dev, dist as ldist, params
@@ -148,6 +149,37 @@ def main():
     sl_bytes = B * N * 2 * 8.0
     sl_gbs = sl_bytes / (sl_ms * 1e-3) / 1e9
 
+    # ---------------------------------------------------------------- third leg: support sweep (C5)
+    # h_S(d) over 1M unit directions on the 4x4 system, s from the stored parameters' (s, alpha) loop at eps = 0.1
+    Phi4 = np.asarray(P["Phi"], dtype=np.float64)
+    Wv = np.asarray(P["W_V"], dtype=np.float64)
+    nd = args.sweep_dirs
+    gen = torch.Generator(device=device); gen.manual_seed(5 + rank)
+    Dd = torch.randn((nd, nx), dtype=torch.float64, device=device, generator=gen)
+    Dd /= Dd.norm(dim=1, keepdim=True)
+    s_sw, a_sw = int(np.ravel(P["mrpi_s"])[0]), float(np.ravel(P["mrpi_alpha"])[0])
+    hout = torch.empty(nd, dtype=torch.float64, device=device)
+    for _ in range(max(1, args.warmup)):
+        dev.support_batch(Phi4, Wv, s_sw, a_sw, Dd, transpose=True, out=hout)
+    barrier()
+    sw_steps = max(10, args.steps)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(sw_steps):
+        dev.support_batch(Phi4, Wv, s_sw, a_sw, Dd, transpose=True, out=hout)
+    e1.record()
+    barrier()
+    sw_ms = e0.elapsed_time(e1) / sw_steps
+    nV = Wv.shape[0]
+    sw_flops = nd * (s_sw * nV * (2.0 * nx + 1.0) + s_sw + 1.0)
+    sw_bytes = nd * 8.0 * (nx + 1)
+    sweep = {"value": nd * world / (sw_ms * 1e-3), "unit": "directions/s", "ms_per_step": sw_ms,
+             "config": {"workload": f"C5: 4x4 support sweep h_S(d), {nd} directions/GPU, s={s_sw}, nV={nV}"},
+             "roofline": {"bound": "valu_fp64", "achieved": sw_flops / (sw_ms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                          "unit": "TFLOP/s", "frac": sw_flops / (sw_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                          "hbm_GBps": sw_bytes / (sw_ms * 1e-3) / 1e9, "traffic": None, "kernel": "support_kernel",
+                          "algorithmic_flops_per_launch": sw_flops, "algorithmic_bytes_per_launch": sw_bytes}}
+
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1 only)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -200,6 +232,7 @@ def main():
                              "roofline": {"bound": "hbm", "achieved": sl_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "frac": sl_gbs / HBM_PEAK_GBS, "traffic": traffic_sl, "kernel": "halfspace_max_kernel",
                                           "algorithmic_bytes_per_launch": sl_bytes}},
+            "support_sweep": sweep,
             "mc_stats": {"infeasible_trials": int(infeas.sum().item()), "max_status": int(status.max().item()),
                          "mean_qp_iters_per_trial": float(iters.double().mean().item())},
             "cpu_baseline": cpu,
