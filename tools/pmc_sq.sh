@@ -2,8 +2,8 @@
 # SQ / instruction-cache counters of the MC kernels at the default bench size (two separate passes)
 cd "$(dirname "$0")/.."
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-rocprofv3 -L 2>/dev/null | grep -o -E "SQC_ICACHE[A-Z_]*|SQ_IFETCH[A-Z_]*|SQ_INST_LEVEL[A-Z_]*|SQ_WAIT_INST_ANY|SQ_INSTS_VALU\b" | sort -u | head -20
-for pass in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_IFETCH" "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES"; do
+PASSES=("$@"); [ ${#PASSES[@]} -eq 0 ] && PASSES=("SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_IFETCH")
+for pass in "${PASSES[@]}"; do
   rm -rf gpurun_out/psq
   timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d gpurun_out/psq -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --sl-sets 64 > gpurun_out/psq.log 2>&1 || { tail -5 gpurun_out/psq.log; continue; }
   python - <<'PY'
