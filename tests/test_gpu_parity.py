@@ -345,3 +345,30 @@ def test_mc_trial_chunks_match_single_launch(core, P, smp):
     for k in one:
         np.testing.assert_array_equal(one[k], many[k], err_msg=k)
     ctx.close()
+
+
+@pytest.mark.parametrize("system", ["2x2", "3x3", "4x4"])
+def test_step_first_pass_filter_is_conservative(core, P, system):
+    """states scattered around the boundary of the tube set alpha*S (gauge 0.5 .. 1 +- 1e-12 .. 1.3): the
+    inscribed-ellipsoid early-out and the packed-fp32 filter in front of the exact solver must never hide a violated
+    row, so statuses, active sets, iteration counts and solutions equal the oracle's (which scans every row in fp64)"""
+    from lbmpc import params
+    Pg = P if system == "2x2" else params.load(system)
+    nx = int(np.ravel(Pg["nx"])[0])
+    SA, Sb = np.asarray(Pg["S_A"], dtype=np.float64), np.asarray(Pg["S_b"], dtype=np.float64).ravel()
+    ctx, octx = core.Context(Pg), oracle_core.Context(Pg)
+    rng = np.random.default_rng(11)
+    B = 1536
+    d = rng.normal(size=(B, nx)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    alpha = rng.uniform(0.05, 1.0, B)
+    gauge = (d @ SA.T / Sb).max(axis=1)                 # boundary of S along d is at d / gauge
+    scale = np.concatenate([rng.uniform(0.5, 0.999, B // 4), 1.0 + rng.choice([-1, 1], B // 4) * 10.0 ** rng.uniform(-13, -6, B // 4),
+                            1.0 + rng.choice([-1, 1], B // 4) * 10.0 ** rng.uniform(-6, -2, B // 4), rng.uniform(1.001, 1.3, B // 4)])
+    # v = 0: x - s0 must lie in alpha*S; x = -q on the scaled boundary
+    X = (d / gauge[:, None]) * (alpha * scale)[:, None]
+    v = np.zeros((B, nx)); w = np.zeros((B, nx))
+    g = ctx.step(X.T, alpha, v.T, w.T, uq_update=False)
+    o = octx.step(X.T, alpha, v.T, w.T, uq_update=False)
+    compare_steps(g, o)
+    assert (o["n_active"] == 0).sum() > B // 8 and (o["n_active"] > 0).sum() > B // 8
+    ctx.close(); octx.close()
