@@ -601,19 +601,6 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
             }
         }
         for (int k = 0; k < K; ++k) {
-            // The two waves of a SIMD are issue-arbitrated oldest first: left alone, waves 4..7 of the block run
-            // 27 % longer than waves 0..3 through the same work and the kernel ends with them.  Alternating the
-            // priority so that the wave that is behind wins splits the advantage evenly.
-            {
-                // progress of this wave, published in a spare word of its solver slot; partner = the other wave of the SIMD
-                volatile int* prog = reinterpret_cast<volatile int*>(ws_base + 47);
-                const int stride = ws_doubles(nz) * 2;  // ints per wave slot
-                if (lane == 0) prog[wave * stride] = k;
-                const int pw = wave ^ 4;
-                const int pk = pw < nwaves ? prog[pw * stride] : k;
-                const bool ahead = k > pk || (k == pk && ((k ^ (wave >> 2)) & 1) == 0);
-                if (ahead) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2);
-            }
             double q[T][NX], xi_lv[T][NX], xi_ev[T][NX], momh[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
