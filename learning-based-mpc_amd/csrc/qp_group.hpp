@@ -106,7 +106,7 @@ __device__ __forceinline__ void mark_rows(bool flag, int p, int nS, int lane, ui
 // slack_S[j] = alpha S_b[j] + S_A[j,:] e ; slack_H[h] = (1-h_k)[h % nc] - H[h,:] z ; strict <, ties -> lowest index.
 template <int NX>
 __device__ __forceinline__ void scan_rows(const CtxDev* __restrict__ C, const LdsView& L, const double* wws,
-                                          double alpha, const double* q, double my_z, const uint32_t* actS,
+                                          double alpha, const double* q, double my_z, bool need, const uint32_t* actS,
                                           const uint32_t* actH, double& best_out, int& bj_out) {
     constexpr int RLc = NX + 1;
     const int lane = lane_id(), grp = lane >> 4;
@@ -159,8 +159,21 @@ __device__ __forceinline__ void scan_rows(const CtxDev* __restrict__ C, const Ld
     {
         const int nchH = ((nH + 127) >> 7) << 1;  // even
         const int nz4 = (nz + 3) >> 2;
+        // Certificate that no H row of this QP can be violated at z: slack_h = (1-h_k)[r] - H[h,:].z >=
+        // min_r (1-h_k)[r] - sum_k max_h|H[h,k]| |z_k| >= 1e-9 (far above the tolerance and the rounding of the exact
+        // evaluation).  A pass over the H rows is skipped when it holds for both of its QPs (rows that do not need a
+        // scan count as certified).
+        bool hskip;
+        {
+            const int i = lane & 15;
+            double t = (i < nz) ? C->cmH[i] * fabs(my_z) : 0.0;
+            t += dpp_f64<0xB1>(t); t += dpp_f64<0x4E>(t); t += dpp_f64<0x141>(t); t += dpp_f64<0x140>(t);
+            const double omin = row_min((i < nc) ? wws[grp * GWS_DOUBLES + i] : LB_INF);
+            hskip = !need || (t <= omin - 1e-9);
+        }
 #pragma unroll
         for (int g0 = 0; g0 < 4; g0 += 2) {
+            if (__builtin_amdgcn_readlane((int)hskip, 16 * g0) && __builtin_amdgcn_readlane((int)hskip, 16 * (g0 + 1))) continue;
             double zu[2][NZMAX];
 #pragma unroll
             for (int gg = 0; gg < 2; ++gg)
@@ -316,7 +329,7 @@ __device__ __forceinline__ void group_qp_solve(const CtxDev* __restrict__ C, con
             ctr[1] += 1;
             double best = -QP_TOL_VIOL;
             int bj = 0x7fffffff;
-            scan_rows<NX>(C, L, gws - grp * GWS_DOUBLES, alpha, q, my_z, actS, actH, best, bj);
+            scan_rows<NX>(C, L, gws - grp * GWS_DOUBLES, alpha, q, my_z, need_scan, actS, actH, best, bj);
             const bool optimal = need_scan && bj == 0x7fffffff;
             const bool newp = need_scan && !optimal;
             done = done || optimal;

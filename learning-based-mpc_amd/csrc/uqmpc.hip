@@ -47,6 +47,7 @@ struct CtxDev {
     // inscribed ellipsoid E = {x : x' ME x <= 1} of S (centred at 0): q' ME q <= (alpha (1-1e-6))^2 proves that no S
     // row is violated at z = 0 (Cauchy-Schwarz: |a_j.q| <= sqrt(a_j' ME^-1 a_j) sqrt(q' ME q) <= b_j alpha (1-1e-6))
     double ME[LBMPC_MAX_NX * LBMPC_MAX_NX], bmin;
+    double cmH[LBMPC_MAX_NZ];  // max_h |H[h,k]|: certificate that no H row is violated (qp_group.hpp, scan_rows)
     int hasE;
     const double* Hm;    // nH x nzp: rows of F_bar Psi^i, i = 0..Nu
     const double* Ginv;  // nz x nz : (2 blkdiag(Px,Pc))^-1
@@ -938,6 +939,8 @@ extern "C" int lbmpc_uqmpc_create(const lbmpc_params* p, lbmpc_ctx** out) {
         }
         M.swap(M2);
     }
+    for (int k = 0; k < LBMPC_MAX_NZ; ++k) h.cmH[k] = 0.0;
+    for (int r = 0; r < nH; ++r) for (int k = 0; k < nz; ++k) h.cmH[k] = std::max(h.cmH[k], std::fabs(Hm[(size_t)r * h.nzp + k]));
     (void)hipGetDevice(&c->device);
     auto fail = [&](hipError_t e, const char* what) { set_error("lbmpc_uqmpc_create: %s -> %s", what, hipGetErrorString(e)); lbmpc_destroy(c); return LBMPC_ERR_HIP; };
     hipError_t e;
