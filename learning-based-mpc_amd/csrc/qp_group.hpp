@@ -73,13 +73,13 @@ __device__ __forceinline__ void row_argmin(double& v, int& idx) {
 
 // coefficients of QP row p (c_p of c_p.z <= d_p) for a per-lane row id: S rows are [-S_A[j,:], 0], H rows F_bar Psi^i.
 // cr[k] = 0 beyond len.  All loads are issued together.
-template <int NX>
+template <int NX, int KB /* compile-time bound on the row length in flight */>
 __device__ __forceinline__ void load_row(const CtxDev* __restrict__ C, const LdsView& L, int p, double* cr, int& len) {
     const bool srow = p < C->nS;
     const double* row = srow ? (L.Srow + p * C->RL + 1) : (L.Hm + (p - C->nS) * C->nzp);
     len = srow ? NX : C->nz;
 #pragma unroll
-    for (int k = 0; k < NZMAX; ++k) {
+    for (int k = 0; k < KB; ++k) {
         const double cv = (k < len) ? row[k] : 0.0;
         cr[k] = srow ? -cv : cv;
     }
@@ -240,15 +240,15 @@ __device__ __forceinline__ void scan_rows(const CtxDev* __restrict__ C, const Ld
 
 // Append row `a` (row-uniform) to the factor: lane b <= a forms M[a][b] = c_b . g_a (c_b = its own active row, g_a
 // broadcast from the lanes holding it), the row solve is a column sweep, lane a gets the diagonal.
-template <int NX>
+template <int NX, int KB>
 __device__ __forceinline__ void chol_append_row(const CtxDev* __restrict__ C, const LdsView& L, bool pred, int a,
                                                 int my_act, double ga /* lane k: g_a[k] */, int i, double* LL,
                                                 double& my_invd) {
-    double cr[NZMAX];
+    double cr[KB];
     int len;
-    load_row<NX>(C, L, (pred && i <= a) ? my_act : 0, cr, len);
+    load_row<NX, KB>(C, L, (pred && i <= a) ? my_act : 0, cr, len);
     double acc = 0.0;
-    static_for<0, NZMAX>([&](auto K) {
+    static_for<0, KB>([&](auto K) {
         constexpr int k = K;
         const double gk = rowb<k>(ga);
         acc = (k < len) ? fma(cr[k], gk, acc) : acc;
@@ -317,6 +317,11 @@ __device__ __forceinline__ void group_qp_solve(const CtxDev* __restrict__ C, con
     double LL[NZMAX], WmK[NZMAX];
 #pragma unroll
     for (int k = 0; k < NZMAX; ++k) { LL[k] = 0.0; WmK[k] = 0.0; }
+    // S rows only touch s0: while no H row is active or pivot in any of the four QPs, every row vector, g = Ginv c
+    // (Ginv is block diagonal) and column of Wm is zero beyond nx, and the k-loops stop at kmax = nx (exact zeros
+    // are skipped, nothing else changes)
+    int hact = 0;  // active H rows of this QP (row-uniform)
+    int kmax = NX;
 
     while (__builtin_amdgcn_ballot_w64(!done) != 0) {
         // ---- Step 1: most violated row at the current z (rows without a pivot) ----
@@ -334,24 +339,29 @@ __device__ __forceinline__ void group_qp_solve(const CtxDev* __restrict__ C, con
             const bool newp = need_scan && !optimal;
             done = done || optimal;
             // c_p, g = Ginv c_p (lane k holds g_k), cg = c_p . g
-            double cp[NZMAX], gi[NZMAX];
-            int len;
-            load_row<NX>(C, L, newp ? bj : 0, cp, len);
-            const int gl = i < nz ? i : 0;
+            if (newp) { p = bj; sp = best; have_p = true; }
+            kmax = (__builtin_amdgcn_ballot_w64(!done && (hact > 0 || (have_p && p >= nS))) != 0) ? nz : NX;
+            double g = 0.0, cgn = 0.0;
+            auto pivot_g = [&](auto KBc) {
+                constexpr int KB = KBc;
+                double cp[KB], gi[KB];
+                int len;
+                load_row<NX, KB>(C, L, newp ? bj : 0, cp, len);
+                const int gl = i < nz ? i : 0;
 #pragma unroll
-            for (int k = 0; k < NZMAX; ++k) gi[k] = (k < nz) ? L.Ginv[gl * nz + k] : 0.0;
-            double g = 0.0;
+                for (int k = 0; k < KB; ++k) gi[k] = (k < nz) ? L.Ginv[gl * nz + k] : 0.0;
 #pragma unroll
-            for (int k = 0; k < NZMAX; ++k) g = (k < len) ? fma(gi[k], cp[k], g) : g;
-            g = i < nz ? g : 0.0;
-            double cgn = 0.0;
-            static_for<0, NZMAX>([&](auto K) {
-                constexpr int k = K;
-                const double gk = rowb<k>(g);
-                cgn = (k < len) ? fma(cp[k], gk, cgn) : cgn;
-            });
+                for (int k = 0; k < KB; ++k) g = (k < len) ? fma(gi[k], cp[k], g) : g;
+                g = i < nz ? g : 0.0;
+                static_for<0, KB>([&](auto K) {
+                    constexpr int k = K;
+                    const double gk = rowb<k>(g);
+                    cgn = (k < len) ? fma(cp[k], gk, cgn) : cgn;
+                });
+            };
+            if (kmax <= NX) pivot_g(std::integral_constant<int, NX>{}); else pivot_g(std::integral_constant<int, NZMAX>{});
             if (newp) {
-                p = bj; sp = best; cg = cgn; my_g = g; have_p = true;
+                cg = cgn; my_g = g;
                 if (i == nq) my_u = 0.0;
             }
         }
@@ -366,14 +376,18 @@ __device__ __forceinline__ void group_qp_solve(const CtxDev* __restrict__ C, con
         // rhs_a = c_a . g (lane a), forward / backward column sweeps with the stored reciprocals
         double my_rhs = 0.0;
         {
-            double cr[NZMAX];
-            int len;
-            load_row<NX>(C, L, (act2 && i < nq) ? my_act : 0, cr, len);
-            static_for<0, NZMAX>([&](auto K) {
-                constexpr int k = K;
-                const double gk = rowb<k>(my_g);
-                my_rhs = (k < len) ? fma(cr[k], gk, my_rhs) : my_rhs;
-            });
+            auto rhs_dot = [&](auto KBc) {
+                constexpr int KB = KBc;
+                double cr[KB];
+                int len;
+                load_row<NX, KB>(C, L, (act2 && i < nq) ? my_act : 0, cr, len);
+                static_for<0, KB>([&](auto K) {
+                    constexpr int k = K;
+                    const double gk = rowb<k>(my_g);
+                    my_rhs = (k < len) ? fma(cr[k], gk, my_rhs) : my_rhs;
+                });
+            };
+            if (kmax <= NX) rhs_dot(std::integral_constant<int, NX>{}); else rhs_dot(std::integral_constant<int, NZMAX>{});
             my_rhs = (act2 && i < nq) ? my_rhs : 0.0;
         }
         // largest active-set size among the four rows (wave-uniform): the sweeps stop there
@@ -445,11 +459,13 @@ __device__ __forceinline__ void group_qp_solve(const CtxDev* __restrict__ C, con
             if (full && i == nq) my_act = p;
 #pragma unroll
             for (int a = 0; a < NZMAX; ++a) WmK[a] = (full && a == nq) ? my_g : WmK[a];
-            chol_append_row<NX>(C, L, full, nq, my_act, my_g, i, LL, my_invd);
+            if (kmax <= NX) chol_append_row<NX, NX>(C, L, full, nq, my_act, my_g, i, LL, my_invd);
+            else chol_append_row<NX, NZMAX>(C, L, full, nq, my_act, my_g, i, LL, my_invd);
             mark_rows(full, p, nS, lane, actS, actH, true);
             if (full) {
                 nq += 1;
                 have_p = false;
+                hact += p >= nS ? 1 : 0;
             }
         }
         GP_T(g3);
@@ -459,29 +475,20 @@ __device__ __forceinline__ void group_qp_solve(const CtxDev* __restrict__ C, con
             // partial / dual-only step: drop active constraint kdrop, stay in step 2 with the same pivot
             const int pd = row_max_i32((drop && i == kdrop) ? my_act : -1);
             mark_rows(drop, pd, nS, lane, actS, actH, false);
+            if (drop) hact -= pd >= nS ? 1 : 0;
             const int nxt_act = dpp_i32<0x101>(my_act);   // row_shl:1 : lane i receives lane i+1
             const double nxt_u = dpp_f64<0x101>(my_u);
             if (drop && i >= kdrop && i < nq) { my_act = nxt_act; my_u = nxt_u; }
 #pragma unroll
             for (int a = 0; a < NZMAX - 1; ++a) WmK[a] = (drop && a >= kdrop && a < nq - 1) ? WmK[a + 1] : WmK[a];
             if (drop) nq -= 1;
-            // rebuild the factor rows kdrop .. nq-1 (their g is recomputed exactly as when they were added)
+            // rebuild the factor rows kdrop .. nq-1; g_a = Ginv c_a of row a is the stored column a of Wm (lane k: WmK[a])
             static_for<0, NZMAX>([&](auto A) {
                 constexpr int a = A;
                 const bool pr = drop && a >= kdrop && a < nq;
                 if (__builtin_amdgcn_ballot_w64(pr) != 0) {
-                    const int pa = rowb_i<a>(my_act);
-                    double cp[NZMAX], gi[NZMAX];
-                    int len;
-                    load_row<NX>(C, L, pr ? pa : 0, cp, len);
-                    const int gl = i < nz ? i : 0;
-#pragma unroll
-                    for (int k = 0; k < NZMAX; ++k) gi[k] = (k < nz) ? L.Ginv[gl * nz + k] : 0.0;
-                    double g = 0.0;
-#pragma unroll
-                    for (int k = 0; k < NZMAX; ++k) g = (k < len) ? fma(gi[k], cp[k], g) : g;
-                    g = i < nz ? g : 0.0;
-                    chol_append_row<NX>(C, L, pr, a, my_act, g, i, LL, my_invd);
+                    if (kmax <= NX) chol_append_row<NX, NX>(C, L, pr, a, my_act, WmK[a], i, LL, my_invd);
+                    else chol_append_row<NX, NZMAX>(C, L, pr, a, my_act, WmK[a], i, LL, my_invd);
                 }
             });
         }
