@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-trials", type=int, default=2048)
     ap.add_argument("--sweep-dirs", type=int, default=1000000)
+    ap.add_argument("--axis-aligned-proposal", action="store_true",
+                    help="rejection-sample xi from the axis-aligned vertex box (the reference's proposal) instead of the principal-axes box")
     args = ap.parse_args()
 
     from lbmpc import core, dev, dist as ldist, params
@@ -59,7 +61,7 @@ def main():
     P = params.load(args.system)
     nx, nz = int(P["nx"]), int(P["nx"]) + int(P["N"]) * int(P["nu"])
     nS, nH = P["S_A"].shape[0], int(P["nc"]) * (int(P["Nu"]) + 1)
-    smp = params.sampler(P)
+    smp = params.sampler(P, oriented=not args.axis_aligned_proposal)   # same distribution on Xi, fewer rejections
     ctx = core.Context(P)
     x0 = np.zeros(nx)
     x0[0], x0[1] = -12.0, 5.0                      # Case_4...:27 x_RM_0, zero-padded
@@ -219,7 +221,8 @@ def main():
             "config": {"workload": f"C4: {args.system} UQ-RMPC closed-loop Monte-Carlo, {args.trials} trials/GPU x "
                                    f"{args.horizon} steps, card(I0)={args.card_i0}, build-generated params_{args.system}.npz",
                        "trials_per_gpu": args.trials, "horizon": args.horizon, "nS": int(nS), "nH": int(nH), "nz": int(nz),
-                       "parallelism": f"trial-sharded x{world}, no data-path collective"},
+                       "parallelism": f"trial-sharded x{world}, no data-path collective",
+                       "xi_proposal": "axis-aligned box" if args.axis_aligned_proposal else "principal-axes box"},
             "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic_mc, "kernel": "mc_kernel (+ mc_sample_kernel pre-pass)",
                          "kernel_ms": kern_ms, "algorithmic_flops_per_launch": flops, "executed": executed,

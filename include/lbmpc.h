@@ -105,6 +105,10 @@ int lbmpc_halfspace_max_dev(const double* WA, int nW, int nx, const double* samp
 
 /* Sampler description: w = xi_EV - xi_LV - B*u_LV with xi_* uniform on {x: Xi_A x <= Xi_b} by
  * rejection from the bounding box [lo, hi] of the vertices, u_LV ~ U[min_u, max_u].
+ * Optional oriented proposal box: with EV_U / LV_U (nx x nx, column-major, invertible) the candidate is x = U t,
+ * t uniform in [lo, hi] (lo, hi then bound the vertices in the coordinates t = U^-1 x); NULL means U = I, the
+ * reference's axis-aligned box.  Either way the accepted samples are uniform on the polytope; a box that fits a
+ * rotated polytope only needs fewer attempts.
  * Replaces Functions_general/InitialSetComputation.m:50-53,101-130 and
  * Functions_general/ModelingCar.m:34-91.  The reference uses MATLAB's unseeded global `rand`;
  * this library defines its own counter-based stream (Philox4x32-10, DESIGN.md "RNG"). */
@@ -122,6 +126,8 @@ typedef struct lbmpc_sampler {
     const double* B;           /* nx x nu  */
     const double* min_u_LV;    /* nu       */
     const double* max_u_LV;    /* nu       */
+    const double* EV_U;        /* nx x nx or NULL: proposal basis of Xi_EV (see above)    */
+    const double* LV_U;        /* nx x nx or NULL                                         */
 } lbmpc_sampler;
 
 /* Draw `batch` information sets of N samples each (set b uses RNG stream (seed, set0 + b)),

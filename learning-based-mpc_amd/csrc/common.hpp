@@ -155,15 +155,39 @@ struct SamplerDev {
     double LV_A[LBMPC_MAX_NXI * LBMPC_MAX_NX], LV_b[LBMPC_MAX_NXI], LV_lo[LBMPC_MAX_NX], LV_hi[LBMPC_MAX_NX];
     double B[LBMPC_MAX_NX * LBMPC_MAX_NU];  // row-major nx x nu
     double min_u[LBMPC_MAX_NU], max_u[LBMPC_MAX_NU];
+    double EV_U[LBMPC_MAX_NX * LBMPC_MAX_NX], LV_U[LBMPC_MAX_NX * LBMPC_MAX_NX];  // row-major proposal bases
+    int EV_hasU, LV_hasU;                                                         // 0: U = I (axis-aligned box)
 };
 int pack_sampler(const lbmpc_sampler* s, SamplerDev* out);  // host: validate + repack
+
+// candidate x = U t, t = lo + (hi - lo) u  (U = I when null)
+template <int NX>
+__device__ __forceinline__ void proposal_point(const double* __restrict__ lo, const double* __restrict__ hi,
+                                               const double* __restrict__ U, const double* u, double* x) {
+    double t[NX];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) t[k] = lo[k] + (hi[k] - lo[k]) * u[k];
+    if (!U) {
+#pragma unroll
+        for (int k = 0; k < NX; ++k) x[k] = t[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc = fma(U[k * NX + i], t[i], acc);
+            x[k] = acc;
+        }
+    }
+}
 
 // Rejection sampling from the vertex bounding box against A x <= b
 // (InitialSetComputation.m:101-122, ModelingCar.m:47-91).  Returns true at the attempt cap.
 template <int NX>
 __device__ __forceinline__ bool sample_polytope(const double* __restrict__ XA, const double* __restrict__ Xb,
                                                 int nr, const double* __restrict__ lo,
-                                                const double* __restrict__ hi, uint64_t seed, uint64_t trial,
+                                                const double* __restrict__ hi, const double* __restrict__ U /* row-major or null */,
+                                                uint64_t seed, uint64_t trial,
                                                 uint32_t index, uint32_t purpose, int max_attempts, double* x) {
     bool done = false;
     for (int a = 0; a < max_attempts; ++a) {
@@ -171,8 +195,7 @@ __device__ __forceinline__ bool sample_polytope(const double* __restrict__ XA, c
             double u[NX + (NX & 1)];
             double xt[NX];
             draw_uniforms<NX>(seed, trial, index, purpose, (uint32_t)a, u);
-#pragma unroll
-            for (int k = 0; k < NX; ++k) xt[k] = lo[k] + (hi[k] - lo[k]) * u[k];
+            proposal_point<NX>(lo, hi, U, u, xt);
             bool ok = true;
             for (int r = 0; r < nr; ++r) {
                 double acc = 0.0;
@@ -221,8 +244,8 @@ __device__ __forceinline__ bool sample_w_I0(const SamplerDev* __restrict__ s, ui
                                             uint32_t i, int max_attempts, double* w) {
     double ev[NX], lv[NX], Bu[NX];
     sample_Bu_lv<NX>(s, seed, set, i, P_I0_U, Bu);
-    bool cap = sample_polytope<NX>(s->EV_A, s->EV_b, s->nEV, s->EV_lo, s->EV_hi, seed, set, i, P_I0_EV, max_attempts, ev);
-    cap |= sample_polytope<NX>(s->LV_A, s->LV_b, s->nLV, s->LV_lo, s->LV_hi, seed, set, i, P_I0_LV, max_attempts, lv);
+    bool cap = sample_polytope<NX>(s->EV_A, s->EV_b, s->nEV, s->EV_lo, s->EV_hi, s->EV_hasU ? s->EV_U : nullptr, seed, set, i, P_I0_EV, max_attempts, ev);
+    cap |= sample_polytope<NX>(s->LV_A, s->LV_b, s->nLV, s->LV_lo, s->LV_hi, s->LV_hasU ? s->LV_U : nullptr, seed, set, i, P_I0_LV, max_attempts, lv);
 #pragma unroll
     for (int k = 0; k < NX; ++k) w[k] = (ev[k] - lv[k]) - Bu[k];
     return cap;

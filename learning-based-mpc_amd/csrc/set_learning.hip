@@ -299,6 +299,11 @@ int pack_sampler(const lbmpc_sampler* s, SamplerDev* o) {
     for (int k = 0; k < s->nx; ++k) { o->EV_lo[k] = s->EV_lo[k]; o->EV_hi[k] = s->EV_hi[k]; o->LV_lo[k] = s->LV_lo[k]; o->LV_hi[k] = s->LV_hi[k]; }
     for (int i = 0; i < s->nx; ++i) for (int j = 0; j < s->nu; ++j) o->B[i * s->nu + j] = s->B[i + (size_t)s->nx * j];
     for (int j = 0; j < s->nu; ++j) { o->min_u[j] = s->min_u_LV[j]; o->max_u[j] = s->max_u_LV[j]; }
+    o->EV_hasU = s->EV_U != nullptr; o->LV_hasU = s->LV_U != nullptr;
+    for (int k = 0; k < s->nx; ++k) for (int i = 0; i < s->nx; ++i) {
+        o->EV_U[k * s->nx + i] = s->EV_U ? s->EV_U[k + (size_t)s->nx * i] : (k == i ? 1.0 : 0.0);
+        o->LV_U[k * s->nx + i] = s->LV_U ? s->LV_U[k + (size_t)s->nx * i] : (k == i ? 1.0 : 0.0);
+    }
     return 0;
 }
 
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(256) void sample_polytope_kernel(PolyDev P, int64_t
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double x[NX];
-    const bool cap = sample_polytope<NX>(P.A, P.b, P.nr, P.lo, P.hi, seed, stream, index0 + (uint32_t)i, purpose, max_attempts, x);
+    const bool cap = sample_polytope<NX>(P.A, P.b, P.nr, P.lo, P.hi, nullptr, seed, stream, index0 + (uint32_t)i, purpose, max_attempts, x);
 #pragma unroll
     for (int k = 0; k < NX; ++k) out[i * NX + k] = x[k];
     if (status) status[i] = cap ? LBMPC_ST_SAMPLER_CAP : 0;

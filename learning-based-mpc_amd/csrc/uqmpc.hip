@@ -461,21 +461,23 @@ __host__ inline size_t xi_bytes_for(int nx, int K, int64_t chunk_n) {
 // in flight).  Every thread serves FOUR adjacent trials, step by step, so that the four accepted draws of a step leave
 // as one contiguous 4*nx*8-byte run of the step-major layout (a full 128-byte line at nx = 4): single 32-byte stores
 // cost as much as the sampling itself.  Same streams and arithmetic as sample_polytope / sample_Bu_lv.
-template <int NX>
-__global__ __launch_bounds__(256) void mc_sample_kernel(SamplerDev smp, int64_t chunk_n, int64_t trial_first, int K,
-                                                        uint64_t seed, int max_attempts, double* __restrict__ xi,
-                                                        int* __restrict__ xi_status) {
-    const int kind = blockIdx.y;
+template <int NX, int KIND>
+__device__ __forceinline__ void mc_sample_body(const SamplerDev& smp, int64_t chunk_n, int64_t trial_first, int K,
+                                               uint64_t seed, int max_attempts, double* __restrict__ xi,
+                                               int* __restrict__ xi_status) {
+    constexpr int kind = KIND;  // compile-time: the fields of the by-value descriptor are read in place (kernarg)
     const int64_t g4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // trials 4 g4 .. 4 g4 + 3 of the chunk
     const int64_t ngroups = (chunk_n + 3) >> 2;
     const bool valid = g4 < ngroups;
     const int64_t cl0 = valid ? 4 * g4 : 0;
-    const double* XA = kind ? smp.EV_A : smp.LV_A;
-    const double* Xb = kind ? smp.EV_b : smp.LV_b;
-    const double* lo = kind ? smp.EV_lo : smp.LV_lo;
-    const double* hi = kind ? smp.EV_hi : smp.LV_hi;
-    const int nr = kind ? smp.nEV : smp.nLV;
-    const uint32_t purpose = kind ? P_ST_EV : P_ST_LV;
+    const double* XA = KIND ? smp.EV_A : smp.LV_A;
+    const double* Xb = KIND ? smp.EV_b : smp.LV_b;
+    const double* lo = KIND ? smp.EV_lo : smp.LV_lo;
+    const double* hi = KIND ? smp.EV_hi : smp.LV_hi;
+    const int nr = KIND ? smp.nEV : smp.nLV;
+    const double* PUm = KIND ? smp.EV_U : smp.LV_U;
+    const bool hasU = KIND ? smp.EV_hasU != 0 : smp.LV_hasU != 0;
+    const uint32_t purpose = KIND ? P_ST_EV : P_ST_LV;
     const int seg = (K + (int)gridDim.z - 1) / (int)gridDim.z;
     const int kbeg = (int)blockIdx.z * seg < K ? (int)blockIdx.z * seg : K;
     const int kend = kbeg + seg < K ? kbeg + seg : K;
@@ -487,8 +489,7 @@ __global__ __launch_bounds__(256) void mc_sample_kernel(SamplerDev smp, int64_t 
             const uint64_t tid = (uint64_t)(trial_first + clj);
             double u[NX + (NX & 1)], xt[NX];
             draw_uniforms<NX>(seed, tid, (uint32_t)k, purpose, (uint32_t)att, u);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) xt[i] = lo[i] + (hi[i] - lo[i]) * u[i];
+            if (hasU) proposal_point<NX>(lo, hi, PUm, u, xt); else proposal_point<NX>(lo, hi, nullptr, u, xt);
             bool ok = true;
             for (int r = 0; r < nr; ++r) {
                 double acc = 0.0;
@@ -529,6 +530,14 @@ __global__ __launch_bounds__(256) void mc_sample_kernel(SamplerDev smp, int64_t 
         }
     }
     (void)st;
+}
+
+template <int NX>
+__global__ __launch_bounds__(256) void mc_sample_kernel(SamplerDev smp, int64_t chunk_n, int64_t trial_first, int K,
+                                                        uint64_t seed, int max_attempts, double* __restrict__ xi,
+                                                        int* __restrict__ xi_status) {
+    if (blockIdx.y == 0) mc_sample_body<NX, 0>(smp, chunk_n, trial_first, K, seed, max_attempts, xi, xi_status);
+    else mc_sample_body<NX, 1>(smp, chunk_n, trial_first, K, seed, max_attempts, xi, xi_status);
 }
 
 #ifdef LBMPC_PROFILE

@@ -25,7 +25,8 @@ class Sampler(C.Structure):
     _fields_ = [("nx", C.c_int), ("nu", C.c_int), ("nEV", C.c_int), ("nLV", C.c_int),
                 ("EV_A", c_double_p), ("EV_b", c_double_p), ("EV_lo", c_double_p), ("EV_hi", c_double_p),
                 ("LV_A", c_double_p), ("LV_b", c_double_p), ("LV_lo", c_double_p), ("LV_hi", c_double_p),
-                ("B", c_double_p), ("min_u_LV", c_double_p), ("max_u_LV", c_double_p)]
+                ("B", c_double_p), ("min_u_LV", c_double_p), ("max_u_LV", c_double_p),
+                ("EV_U", c_double_p), ("LV_U", c_double_p)]
 
 
 class Params(C.Structure):
@@ -77,10 +78,33 @@ class Keep:
         return C.byref(self.struct)
 
 
-def make_sampler(nx, nu, EV_A, EV_b, EV_V, LV_A, LV_b, LV_V, B, min_u, max_u):
-    arr = dict(EV_A=fcol(EV_A), EV_b=fcol(EV_b).ravel(), EV_lo=fcol(np.min(EV_V, 0)), EV_hi=fcol(np.max(EV_V, 0)),
-               LV_A=fcol(LV_A), LV_b=fcol(LV_b).ravel(), LV_lo=fcol(np.min(LV_V, 0)), LV_hi=fcol(np.max(LV_V, 0)),
+def oriented_box(V):
+    """Proposal box of a polytope with vertices V (rows): the principal axes of the vertex cloud when that box is
+    smaller than the axis-aligned one (a rotated cuboid is then sampled without rejections), else None.
+    Returns (U, lo, hi): candidates are x = U t, t uniform in [lo, hi]."""
+    V = np.asarray(V, dtype=np.float64)
+    lo0, hi0 = V.min(0), V.max(0)
+    c = V.mean(0)
+    _, U = np.linalg.eigh((V - c).T @ (V - c))
+    T = V @ U                       # coordinates t = U' x (U orthonormal)
+    lo, hi = T.min(0), T.max(0)
+    if np.prod(hi - lo) < 0.9 * np.prod(hi0 - lo0):
+        return np.ascontiguousarray(U), lo, hi
+    return None, lo0, hi0
+
+
+def make_sampler(nx, nu, EV_A, EV_b, EV_V, LV_A, LV_b, LV_V, B, min_u, max_u, oriented=False):
+    """oriented=False: the reference's axis-aligned bounding box of the vertices (ModelingCar.m:50-51);
+    oriented=True: principal-axes box where it is tighter (same distribution, fewer rejections)."""
+    boxes = {}
+    for name, V in (("EV", EV_V), ("LV", LV_V)):
+        boxes[name] = oriented_box(V) if oriented else (None, np.min(V, 0), np.max(V, 0))
+    arr = dict(EV_A=fcol(EV_A), EV_b=fcol(EV_b).ravel(), EV_lo=fcol(boxes["EV"][1]), EV_hi=fcol(boxes["EV"][2]),
+               LV_A=fcol(LV_A), LV_b=fcol(LV_b).ravel(), LV_lo=fcol(boxes["LV"][1]), LV_hi=fcol(boxes["LV"][2]),
                B=fcol(np.reshape(B, (nx, nu))), min_u_LV=fcol(np.ravel(min_u)), max_u_LV=fcol(np.ravel(max_u)))
+    for name in ("EV", "LV"):
+        if boxes[name][0] is not None:
+            arr[name + "_U"] = fcol(boxes[name][0])
     s = Sampler(nx=nx, nu=nu, nEV=arr["EV_A"].shape[0], nLV=arr["LV_A"].shape[0],
                 **{k: dptr(v) for k, v in arr.items()})
     return Keep(s, arr)

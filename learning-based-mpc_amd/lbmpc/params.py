@@ -22,8 +22,10 @@ def load(name_or_path):
     return d
 
 
-def sampler(d):
+def sampler(d, oriented=False):
+    """oriented=True: principal-axes proposal boxes where they are tighter than the reference's axis-aligned ones
+    (lbmpc_sampler.EV_U / LV_U): same uniform distribution on Xi, fewer rejections."""
     nx, nu = int(d["nx"]), int(d["nu"])
     return _abi.make_sampler(nx=nx, nu=nu, EV_A=d["Xi_EV_H"][:, :-1], EV_b=d["Xi_EV_H"][:, -1], EV_V=d["Xi_EV_V"],
                              LV_A=d["Xi_LV_H"][:, :-1], LV_b=d["Xi_LV_H"][:, -1], LV_V=d["Xi_LV_V"], B=d["B"],
-                             min_u=d["min_u_LV"], max_u=d["max_u_LV"])
+                             min_u=d["min_u_LV"], max_u=d["max_u_LV"], oriented=oriented)

@@ -44,6 +44,10 @@ static void fill_sampler(const mxArray* s, lbmpc_sampler* o) {
     o->LV_A = dbl(field(s, "LV_A")); o->LV_b = dbl(field(s, "LV_b")); o->nLV = rows(field(s, "LV_A"));
     o->LV_lo = dbl(field(s, "LV_lo")); o->LV_hi = dbl(field(s, "LV_hi"));
     o->B = dbl(field(s, "B")); o->min_u_LV = dbl(field(s, "min_u_LV")); o->max_u_LV = dbl(field(s, "max_u_LV"));
+    const mxArray* eu = mxGetField(s, 0, "EV_U");   // optional oriented proposal boxes
+    const mxArray* lu = mxGetField(s, 0, "LV_U");
+    o->EV_U = (eu && !mxIsEmpty(eu)) ? dbl(eu) : nullptr;
+    o->LV_U = (lu && !mxIsEmpty(lu)) ? dbl(lu) : nullptr;
 }
 
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {

@@ -73,12 +73,18 @@ static void draw_uniforms(uint64_t seed, uint64_t trial, uint32_t index, uint32_
 /* Rejection sampling from the bounding box of the vertices against A x <= b:
  * InitialSetComputation.m:101-122, ModelingCar.m:47-91.  Returns 0, or 1 at the attempt cap. */
 static int sample_polytope(const double* XA, const double* Xb, int nr, const double* lo,
-                           const double* hi, int nx, uint64_t seed, uint64_t trial, uint32_t index,
-                           uint32_t purpose, int max_attempts, double* x) {
-    double u[LBMPC_MAX_NX];
+                           const double* hi, const double* U /* nx x nx col-major or NULL */, int nx, uint64_t seed,
+                           uint64_t trial, uint32_t index, uint32_t purpose, int max_attempts, double* x) {
+    double u[LBMPC_MAX_NX], t[LBMPC_MAX_NX];
     for (int a = 0; a < max_attempts; ++a) {
         draw_uniforms(seed, trial, index, purpose, (uint32_t)a, nx, u);
-        for (int k = 0; k < nx; ++k) x[k] = lo[k] + (hi[k] - lo[k]) * u[k];
+        for (int k = 0; k < nx; ++k) t[k] = lo[k] + (hi[k] - lo[k]) * u[k];
+        for (int k = 0; k < nx; ++k) {
+            if (!U) { x[k] = t[k]; continue; }
+            double acc = 0.0;
+            for (int i = 0; i < nx; ++i) acc = fma(CM(U, nx, k, i), t[i], acc);
+            x[k] = acc;
+        }
         int ok = 1;
         for (int r = 0; r < nr; ++r) {
             double acc = 0.0;
@@ -111,8 +117,8 @@ static int sample_w_I0(const lbmpc_sampler* s, uint64_t seed, uint64_t set, uint
     double u[LBMPC_MAX_NZ], ev[LBMPC_MAX_NX], lv[LBMPC_MAX_NX], Bu[LBMPC_MAX_NX];
     int st = 0;
     sample_u_lv(s, seed, set, i, P_I0_U, u);
-    st |= sample_polytope(s->EV_A, s->EV_b, s->nEV, s->EV_lo, s->EV_hi, s->nx, seed, set, i, P_I0_EV, max_attempts, ev);
-    st |= sample_polytope(s->LV_A, s->LV_b, s->nLV, s->LV_lo, s->LV_hi, s->nx, seed, set, i, P_I0_LV, max_attempts, lv);
+    st |= sample_polytope(s->EV_A, s->EV_b, s->nEV, s->EV_lo, s->EV_hi, s->EV_U, s->nx, seed, set, i, P_I0_EV, max_attempts, ev);
+    st |= sample_polytope(s->LV_A, s->LV_b, s->nLV, s->LV_lo, s->LV_hi, s->LV_U, s->nx, seed, set, i, P_I0_LV, max_attempts, lv);
     mat_vec(s->B, s->nx, s->nu, u, Bu);
     for (int k = 0; k < s->nx; ++k) w[k] = (ev[k] - lv[k]) - Bu[k];
     return st;
@@ -274,7 +280,7 @@ int orc_sample_polytope(const double* XA, const double* Xb, int nr, int nx, cons
                         double* out, int* status_out) {
     if (nx > LBMPC_MAX_NX || nr > LBMPC_MAX_NXI) return LBMPC_ERR_DIM;
     for (int64_t i = 0; i < n; ++i) {
-        int cap = sample_polytope(XA, Xb, nr, lo, hi, nx, seed, stream, index0 + (uint32_t)i, (uint32_t)purpose, max_attempts, out + (size_t)i * nx);
+        int cap = sample_polytope(XA, Xb, nr, lo, hi, NULL, nx, seed, stream, index0 + (uint32_t)i, (uint32_t)purpose, max_attempts, out + (size_t)i * nx);
         if (status_out) status_out[i] = cap ? LBMPC_ST_SAMPLER_CAP : 0;
     }
     return 0;
@@ -829,7 +835,7 @@ int orc_mc_run(orc_ctx* c, const lbmpc_sampler* smp, const lbmpc_mc_cfg* cfg, lb
         for (int k = 0; k < K; ++k) {
             double xi_lv[LBMPC_MAX_NX], xi_ev[LBMPC_MAX_NX], u_lv[LBMPC_MAX_NZ], w_new[LBMPC_MAX_NX];
             /* LVModeling first (Case_3...:58; ModelingCar.m:42-43) */
-            if (sample_polytope(smp->LV_A, smp->LV_b, smp->nLV, smp->LV_lo, smp->LV_hi, nx, cfg->seed, tid, (uint32_t)k, P_ST_LV, cfg->sampler_max_attempts, xi_lv)) status = status > LBMPC_ST_SAMPLER_CAP ? status : LBMPC_ST_SAMPLER_CAP;
+            if (sample_polytope(smp->LV_A, smp->LV_b, smp->nLV, smp->LV_lo, smp->LV_hi, smp->LV_U, nx, cfg->seed, tid, (uint32_t)k, P_ST_LV, cfg->sampler_max_attempts, xi_lv)) status = status > LBMPC_ST_SAMPLER_CAP ? status : LBMPC_ST_SAMPLER_CAP;
             sample_u_lv(smp, cfg->seed, tid, (uint32_t)k, P_ST_U, u_lv);
             if (k == 0) for (int i = 0; i < nx; ++i) w_new[i] = 0.0; /* Case_3...:62-65 */
             else {
@@ -845,7 +851,7 @@ int orc_mc_run(orc_ctx* c, const lbmpc_sampler* smp, const lbmpc_mc_cfg* cfg, lb
             iters_total += it;
             alpha = a2; memcpy(v, v2, sizeof(double) * nx);
             /* EVModeling (ModelingCar.m:36-37) */
-            if (sample_polytope(smp->EV_A, smp->EV_b, smp->nEV, smp->EV_lo, smp->EV_hi, nx, cfg->seed, tid, (uint32_t)k, P_ST_EV, cfg->sampler_max_attempts, xi_ev)) status = status > LBMPC_ST_SAMPLER_CAP ? status : LBMPC_ST_SAMPLER_CAP;
+            if (sample_polytope(smp->EV_A, smp->EV_b, smp->nEV, smp->EV_lo, smp->EV_hi, smp->EV_U, nx, cfg->seed, tid, (uint32_t)k, P_ST_EV, cfg->sampler_max_attempts, xi_ev)) status = status > LBMPC_ST_SAMPLER_CAP ? status : LBMPC_ST_SAMPLER_CAP;
             double Ax[LBMPC_MAX_NX], Bu[LBMPC_MAX_NX], Bul[LBMPC_MAX_NX], xn[LBMPC_MAX_NX];
             mat_vec(c->A, nx, nx, x, Ax);
             mat_vec(c->B, nx, nu, u, Bu);

@@ -372,3 +372,28 @@ def test_step_first_pass_filter_is_conservative(core, P, system):
     compare_steps(g, o)
     assert (o["n_active"] == 0).sum() > B // 8 and (o["n_active"] > 0).sum() > B // 8
     ctx.close(); octx.close()
+
+
+@pytest.mark.parametrize("system,x0", [("3x3", [-12.0, 5.0, 0.0]), ("4x4", [-12.0, 5.0, 0.0, 0.0])])
+def test_mc_oriented_proposal_vs_oracle(core, system, x0):
+    """lbmpc_sampler.EV_U / LV_U (principal-axes proposal boxes): closed loop vs oracle on the same streams, and the
+    accepted disturbances keep the distribution of the axis-aligned proposal (uniform on Xi): first two moments of
+    the learned w samples agree within Monte-Carlo error"""
+    from lbmpc import params
+    Pg = params.load(system)
+    nx = len(x0)
+    ctx, octx = core.Context(Pg), oracle_core.Context(Pg)
+    kw = dict(trials=200, steps=25, card_I0=10, seed=4, x0=x0, acc_bound=float(Pg["acc_bound"][0]),
+              distance_error=float(Pg["distance_error"][0]), traj_trials=200)
+    so = params.sampler(Pg, oriented=True)
+    assert so.struct.EV_U and so.struct.LV_U     # both boxes are oriented for these systems
+    compare_mc(ctx.mc_run(so, **kw), octx.mc_run(so, **kw))
+    WA = np.asarray(Pg["W_H"])[:, :-1]
+    N = 40000
+    sa, _, _ = core.sample_information_sets(params.sampler(Pg), WA, N, 1, seed=3)
+    sb, _, _ = core.sample_information_sets(so, WA, N, 1, seed=3)
+    sa, sb = np.asarray(sa)[0], np.asarray(sb)[0]     # nx x N
+    sd = sa.std(axis=1)
+    assert np.all(np.abs(sa.mean(1) - sb.mean(1)) < 5 * sd / np.sqrt(N) * 1.5)
+    assert np.allclose(np.cov(sa), np.cov(sb), rtol=0.06, atol=0.02 * sd.max() ** 2)
+    ctx.close(); octx.close()
