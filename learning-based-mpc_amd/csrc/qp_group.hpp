@@ -238,6 +238,53 @@ __device__ __forceinline__ void scan_rows(const CtxDev* __restrict__ C, const Ld
     }
 }
 
+// Most violated candidate row of this QP (row-local): lane i evaluates cand0 and cand1 with the arithmetic of the full
+// scan (so the value equals the oracle's row_slack bit for bit), rows already active are skipped, (value, row) arg-min
+// with ties to the lowest row.
+template <int NX>
+__device__ __forceinline__ void candidate_pivot(const CtxDev* __restrict__ C, const LdsView& L, const double* gws, double alpha,
+                                                const double* q, double my_z, int my_act, int nq, bool need, int cand0,
+                                                int cand1, double& best, int& bj) {
+    const int i = lane_id() & 15;
+    const int nS = C->nS, nc = C->nc, nz = C->nz, nzp = C->nzp;
+    double e[NX];
+    static_for<0, NX>([&](auto K) { constexpr int k = K; e[k] = q[k] + rowb<k>(my_z); });
+    bool act0 = false, act1 = false;
+    static_for<0, NZMAX>([&](auto A) {
+        constexpr int a = A;
+        const int ra = rowb_i<a>(my_act);
+        act0 = act0 || (a < nq && ra == cand0);
+        act1 = act1 || (a < nq && ra == cand1);
+    });
+    const bool v0 = need && cand0 >= 0 && !act0, v1 = need && cand1 >= 0 && !act1;
+    double s0v = LB_INF, s1v = LB_INF;
+    {   // S-type candidate (cand1 is never an S row)
+        const int j = (v0 && cand0 < nS) ? cand0 : 0;
+        const double* row = L.Srow + j * (NX + 1);
+        double acc = alpha * row[0];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) acc = fma(row[1 + k], e[k], acc);
+        if (v0 && cand0 < nS) s0v = acc;
+    }
+    if (__builtin_amdgcn_ballot_w64((v0 && cand0 >= nS) || v1) != 0) {  // H-type candidates
+        double zr[NZMAX];
+        static_for<0, NZMAX>([&](auto K) { constexpr int k = K; zr[k] = rowb<k>(my_z); });
+        const int h0 = (v0 && cand0 >= nS) ? cand0 - nS : 0, h1 = v1 ? cand1 - nS : 0;
+        const double* r0 = L.Hm + h0 * nzp;
+        const double* r1 = L.Hm + h1 * nzp;
+        double a0 = gws[h0 % nc], a1 = gws[h1 % nc];
+#pragma unroll
+        for (int k = 0; k < NZMAX; ++k)
+            if (k < nz) { a0 = fma(-r0[k], zr[k], a0); a1 = fma(-r1[k], zr[k], a1); }
+        if (v0 && cand0 >= nS) s0v = a0;
+        if (v1) s1v = a1;
+    }
+    if (v0 && s0v < best) { best = s0v; bj = cand0; }
+    if (v1 && (s1v < best || (s1v == best && cand1 < bj))) { best = s1v; bj = cand1; }
+    row_argmin(best, bj);
+    if (!(best < -QP_TOL_VIOL)) bj = 0x7fffffff;
+}
+
 // Append row `a` (row-uniform) to the factor: lane b <= a forms M[a][b] = c_b . g_a (c_b = its own active row, g_a
 // broadcast from the lanes holding it), the row solve is a column sweep, lane a gets the diagonal.
 template <int NX, int KB>
@@ -295,6 +342,8 @@ __device__ __forceinline__ void chol_append_row(const CtxDev* __restrict__ C, co
 template <int NX>
 __device__ __forceinline__ void group_qp_solve(const CtxDev* __restrict__ C, const LdsView& L, double* gws, bool live,
                                                double alpha, const double* q, unsigned* ctr /* [0] trips, [1] scans (wave-uniform) */,
+                                               int* hint_rows /* this row's 16 candidate slots in HBM, or null */,
+                                               int* hint_n /* their count (in: previous step, out: this solve) */,
                                                long long* prof = nullptr) {
 #ifdef LBMPC_PROFILE
 #define GP_T(var) const long long var = clock64()
@@ -322,6 +371,14 @@ __device__ __forceinline__ void group_qp_solve(const CtxDev* __restrict__ C, con
     // are skipped, nothing else changes)
     int hact = 0;  // active H rows of this QP (row-uniform)
     int kmax = NX;
+    // Pivot candidates (oracle qp_solve): the final active set of the trial's previous closed-loop step; lane i holds
+    // candidate i and, for an H row, its one-step-earlier twin.
+    int cand0 = -1, cand1 = -1;
+    if (live && hint_rows) {
+        const int nh = *hint_n;
+        cand0 = i < nh ? hint_rows[i] : -1;
+        cand1 = cand0 >= nS + C->nc ? cand0 - C->nc : -1;
+    }
 
     while (__builtin_amdgcn_ballot_w64(!done) != 0) {
         // ---- Step 1: most violated row at the current z (rows without a pivot) ----
@@ -330,11 +387,24 @@ __device__ __forceinline__ void group_qp_solve(const CtxDev* __restrict__ C, con
         GP_INC(4);
         ctr[0] += 1;
         if (__builtin_amdgcn_ballot_w64(need_scan) != 0) {
-            GP_INC(5);
-            ctr[1] += 1;
             double best = -QP_TOL_VIOL;
             int bj = 0x7fffffff;
-            scan_rows<NX>(C, L, gws - grp * GWS_DOUBLES, alpha, q, my_z, need_scan, actS, actH, best, bj);
+            // candidates first: while one of them is violated no pass over all the rows is needed
+            bool need_full = need_scan;
+            if (__builtin_amdgcn_ballot_w64(need_scan && cand0 >= 0) != 0) {
+                double cb = -QP_TOL_VIOL;
+                int cj = 0x7fffffff;
+                candidate_pivot<NX>(C, L, gws, alpha, q, my_z, my_act, nq, need_scan, cand0, cand1, cb, cj);
+                if (need_scan && cj != 0x7fffffff) { best = cb; bj = cj; need_full = false; }
+            }
+            if (__builtin_amdgcn_ballot_w64(need_full) != 0) {
+                GP_INC(5);
+                ctr[1] += 1;
+                double fb = -QP_TOL_VIOL;
+                int fj = 0x7fffffff;
+                scan_rows<NX>(C, L, gws - grp * GWS_DOUBLES, alpha, q, my_z, need_full, actS, actH, fb, fj);
+                if (need_full) { best = fb; bj = fj; }
+            }
             const bool optimal = need_scan && bj == 0x7fffffff;
             const bool newp = need_scan && !optimal;
             done = done || optimal;
@@ -494,6 +564,10 @@ __device__ __forceinline__ void group_qp_solve(const CtxDev* __restrict__ C, con
         }
         GP_T(g4);
         GP_ADD(3, g3, g4);
+    }
+    if (live && hint_rows) {  // this solve's active set = the next step's candidates
+        if (i < nq) hint_rows[i] = my_act;
+        if (i == 0) *hint_n = nq;
     }
     // results -> this row's LDS slot
     gws[16 + i] = my_z;

@@ -68,6 +68,8 @@ struct lbmpc_ctx {
     int* xi_status = nullptr;
     size_t xi_status_n = 0;
     unsigned long long* counters = nullptr;  // 8 work counters of the last mc_run
+    int* hint = nullptr;                     // pivot candidates, 17 ints per chunk trial (16 rows + count)
+    size_t hint_n = 0;
     double* park = nullptr;                  // state parked during solves, PARK_SLOTS doubles per grid thread
     size_t park_bytes = 0;
 };
@@ -282,6 +284,8 @@ __device__ __forceinline__ void solve_flagged(const CtxDev* __restrict__ C, cons
                                               double* s0, double* c0, int& status, int& iters,
                                               int* nact_out, int* act_out /* NZMAX, sorted, or null */,
                                               double* c_full /* nz-NX or null */, unsigned* ctr /* [0] solves [1] rounds [2] trips [3] scans */,
+                                              int* hint_base /* [chunk trial][16] pivot candidates in HBM, or null */,
+                                              int* nhint_base /* [chunk trial] */, int cl /* this lane's chunk trial */,
                                               long long* prof = nullptr) {
     const int lane = lane_id(), grp = lane >> 4;
     uint64_t mask = __builtin_amdgcn_ballot_w64(need);
@@ -298,7 +302,7 @@ __device__ __forceinline__ void solve_flagged(const CtxDev* __restrict__ C, cons
         double a_g = 0.0, q_g[NX];
 #pragma unroll
         for (int k = 0; k < NX; ++k) q_g[k] = 0.0;
-        int mygrp = -1;
+        int mygrp = -1, cl_g = 0;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int sl = src[g] < 0 ? 0 : src[g];
@@ -307,12 +311,15 @@ __device__ __forceinline__ void solve_flagged(const CtxDev* __restrict__ C, cons
 #pragma unroll
             for (int k = 0; k < NX; ++k) { const double qr = readlane_f64(q[k], sl); q_g[k] = grp == g ? qr : q_g[k]; }
             if (lane == src[g]) mygrp = g;
+            const int clr = __builtin_amdgcn_readlane(cl, sl);
+            cl_g = grp == g ? clr : cl_g;
         }
         const bool live = (grp == 0 ? src[0] : grp == 1 ? src[1] : grp == 2 ? src[2] : src[3]) >= 0;
         if (mygrp >= 0)
             for (int r = 0; r < C->nc; ++r) wws[mygrp * GWS_DOUBLES + r] = 1.0 - hk_value<NX>(C, alpha, v, r);
         wave_sync();
-        group_qp_solve<NX>(C, L, wws + grp * GWS_DOUBLES, live, a_g, q_g, ctr + 2, prof);
+        group_qp_solve<NX>(C, L, wws + grp * GWS_DOUBLES, live, a_g, q_g, ctr + 2,
+                           hint_base ? hint_base + (int64_t)cl_g * 16 : nullptr, nhint_base ? nhint_base + cl_g : nullptr, prof);
         wave_sync();
         if (mygrp >= 0) {
             const double* gw = wws + mygrp * GWS_DOUBLES;
@@ -381,7 +388,7 @@ __global__ __launch_bounds__(256) void uqmpc_step_kernel(const CtxDev* __restric
         if (valid && io.active_set) for (int a = 0; a < NZMAX; ++a) io.active_set[b * NZMAX + a] = -1;
         unsigned ctr[4] = {0, 0, 0, 0};
         solve_flagged<NX>(C, L, ws, valid && need[0], alpha[0], v, q[0], s0, c0, status, iters,
-                          &nact, (valid && io.active_set) ? io.active_set + b * NZMAX : nullptr, cdst, ctr);
+                          &nact, (valid && io.active_set) ? io.active_set + b * NZMAX : nullptr, cdst, ctr, nullptr, nullptr, 0);
         (void)act_sorted;
         if (!valid) continue;
         if (io.s0) for (int k = 0; k < NX; ++k) io.s0[b * NX + k] = s0[k];
@@ -436,6 +443,8 @@ struct McArgs {
     const double* xi;       // pre-drawn xi_LV / xi_EV, layout xi_index()
     const int* xi_status;   // [chunk trial] LBMPC_ST_SAMPLER_CAP if a step sampler hit the attempt cap
     unsigned long long* counters;  // 8 work counters of this launch
+    int* hint;              // [chunk trial][16] final active set of the trial's previous step (pivot candidates)
+    int* nhint;             // [chunk trial] its size
     double* park;           // [slot][thread of the grid]: closed-loop state parked during a solve (mc_kernel)
     lbmpc_mc_out out;
 };
@@ -573,6 +582,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
         bool valid[T];
         double x[T][NX], wst[T][NX], v[T][NX], alpha[T];
         int status[T], infeasible[T], iters[T];
+        bool hashint[T];   // the trial's candidate list in HBM is non-empty
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int64_t l = base + t * LB_WAVE + lane;
@@ -580,7 +590,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
             cl[t] = valid[t] ? l : a.chunk_n - 1;
             tl[t] = a.chunk0 + cl[t];
             tid[t] = (uint64_t)(a.trial0 + tl[t]);
-            status[t] = a.steps > 0 ? a.xi_status[cl[t]] : 0; infeasible[t] = 0; iters[t] = 0;
+            status[t] = a.steps > 0 ? a.xi_status[cl[t]] : 0; infeasible[t] = 0; iters[t] = 0; hashint[t] = false;
             // initial set learning: InitialSetComputation.solve (:48-59), card_I0 samples
             double m[2 * NX];
 #pragma unroll
@@ -675,8 +685,11 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
                     double v_t[NX], q_t[NX];
 #pragma unroll
                     for (int i = 0; i < NX; ++i) { v_t[i] = v[t][i]; q_t[i] = q[t][i]; }
+                    int nact_t = 0;
                     solve_flagged<NX>(C, L, ws, valid[t] && need[t], a_t, v_t, q_t, s0, c0,
-                                      status[t], iters[t], nullptr, nullptr, nullptr, ctr + 2, PROF_PTR);
+                                      status[t], iters[t], &nact_t, nullptr, nullptr, ctr + 2, a.hint, a.nhint,
+                                      (int)cl[t], PROF_PTR);
+                    if (valid[t] && need[t]) hashint[t] = nact_t > 0;
                     asm volatile("" : "+v"(pk));
                     slot = 0;
 #pragma unroll
@@ -692,6 +705,8 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
                         tid[tt] = (uint64_t)__double_as_longlong(pk[(slot++) * ps]);
                     }
                 }
+                // no QP this step = the oracle's trivial solve with an empty active set: no candidates next step
+                if (valid[t] && !need[t] && hashint[t]) { a.nhint[cl[t]] = 0; hashint[t] = false; }
                 PROF_T(p4);
                 PROF_ADD(2, p3, p4);
                 // u = K x + c(1:nu); EVModeling (ModelingCar.m:36-37); relative dynamics
@@ -864,6 +879,7 @@ extern "C" void lbmpc_destroy(lbmpc_ctx* c) {
     if (c->xi_status) (void)hipFree(c->xi_status);
     if (c->counters) (void)hipFree(c->counters);
     if (c->park) (void)hipFree(c->park);
+    if (c->hint) (void)hipFree(c->hint);
     delete c;
 }
 
@@ -1095,10 +1111,18 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
     }
     if (!c->counters) LB_HIP(hipMalloc((void**)&c->counters, 8 * sizeof(unsigned long long)));
     LB_HIP(hipMemsetAsync(c->counters, 0, 8 * sizeof(unsigned long long), st));
+    if ((size_t)chunk > c->hint_n) {
+        if (c->hint) LB_HIP(hipFree(c->hint));
+        c->hint = nullptr; c->hint_n = 0;
+        LB_HIP(hipMalloc((void**)&c->hint, (size_t)chunk * 17 * sizeof(int)));
+        c->hint_n = (size_t)chunk;
+    }
+    a.hint = c->hint; a.nhint = c->hint + (size_t)c->hint_n * 16;
     a.xi = c->xi; a.xi_status = c->xi_status; a.counters = c->counters;
     for (int64_t c0 = 0; c0 < cfg->trials; c0 += chunk) {
         const int64_t cn = cfg->trials - c0 < chunk ? cfg->trials - c0 : chunk;
         a.chunk0 = c0; a.chunk_n = cn;
+        LB_HIP(hipMemsetAsync(a.nhint, 0, (size_t)cn * sizeof(int), st));
         if (cfg->steps > 0) {
             LB_HIP(hipMemsetAsync(c->xi_status, 0, (size_t)cn * sizeof(int), st));
             // enough segments to put about 8 waves on every SIMD

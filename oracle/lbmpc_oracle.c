@@ -589,8 +589,14 @@ static void row_coeffs(const orc_ctx* c, int j, double* cj) { /* c_j of c_j.z <=
 /* Goldfarb-Idnani dual active-set method (Math. Prog. 27, 1983) for
  *   min z' P z  s.t.  rows above,   P = blkdiag(Px, Pc)   (UQRobustMPC.m:149-155)
  * started from the unconstrained minimiser z = 0 with an empty active set.  Replaces IPOPT. */
+/* Pivot rule: candidate rows first.  `hint` (nhint rows, may be NULL) is the final active set of the previous
+ * closed-loop step of the same trial; each H row of it also proposes its one-step-earlier twin (row - nc: the
+ * prediction step index shifts by one per closed-loop step).  While any candidate that is not active is violated
+ * the most violated one (ties: lowest row) is the pivot and no full pass over the rows is needed; otherwise the
+ * most violated row of all (ties: lowest row).  Any rule that picks violated rows reaches the same, unique
+ * minimiser; this one needs fewer full passes along a trajectory. */
 static int qp_solve(const orc_ctx* c, const double* q, double alpha, const double* omh, double* z,
-                    int* act, double* lam, int* nact_out, int* iters_out) {
+                    int* act, double* lam, int* nact_out, int* iters_out, const int* hint, int nhint) {
     int nz = c->nz, nx = c->nx, m = c->m, nq = 0, iters = 0, status = 0;
     double CA[LBMPC_MAX_NZ][LBMPC_MAX_NZ]; /* active rows */
     double Wm[LBMPC_MAX_NZ][LBMPC_MAX_NZ]; /* Wm[a] = Ginv c_a */
@@ -602,6 +608,17 @@ static int qp_solve(const orc_ctx* c, const double* q, double alpha, const doubl
         for (int k = 0; k < nx; ++k) e[k] = q[k] + z[k];
         int p = -1;
         double sp = -QP_TOL_VIOL;
+        for (int hh = 0; hh < nhint; ++hh)
+            for (int tw = 0; tw < 2; ++tw) {
+                int j = hint[hh];
+                if (tw) { if (j < c->nS + c->nc) continue; j -= c->nc; }
+                int isact = 0;
+                for (int a = 0; a < nq; ++a) if (act[a] == j) isact = 1;
+                if (isact) continue;
+                double s = row_slack(c, j, e, alpha, omh, z);
+                if (s < sp || (s == sp && p >= 0 && j < p)) { sp = s; p = j; }
+            }
+        if (p < 0)
         for (int j = 0; j < m; ++j) {
             int isact = 0;
             for (int a = 0; a < nq; ++a) if (act[a] == j) isact = 1;
@@ -711,7 +728,8 @@ done:
 static int step_one(const orc_ctx* c, int uq_update, const double* x, double alpha_prev,
                     const double* v_prev, const double* w_new, double* s0, double* cc, double* u,
                     double* alpha_out, double* v_out, double* hk, double* Sb_hat, double* Wb_hat,
-                    int* n_active, int* active_set, int* qp_iters) {
+                    int* n_active, int* active_set, int* qp_iters, int* hint /* in: previous, out: this step's */,
+                    int* nhint) {
     int nx = c->nx, nW = c->nW, nz = c->nz, status = 0;
     double alpha = alpha_prev, v[LBMPC_MAX_NX], bh[LBMPC_MAX_NW];
     memcpy(v, v_prev, sizeof(double) * nx);
@@ -753,7 +771,8 @@ static int step_one(const orc_ctx* c, int uq_update, const double* x, double alp
     for (int k = 0; k < nx; ++k) q[k] = beta * Tv[k] - x[k];
     double z[LBMPC_MAX_NZ], lam[LBMPC_MAX_NZ];
     int act[LBMPC_MAX_NZ], nact = 0, iters = 0;
-    int st = qp_solve(c, q, alpha, omh, z, act, lam, &nact, &iters);
+    int st = qp_solve(c, q, alpha, omh, z, act, lam, &nact, &iters, hint, nhint ? *nhint : 0);
+    if (hint && nhint) { for (int a = 0; a < nact; ++a) hint[a] = act[a]; *nhint = nact; }
     if (st > status) status = st;
     if (s0) memcpy(s0, z, sizeof(double) * nx);
     if (cc) memcpy(cc, z + nx, sizeof(double) * (nz - nx));
@@ -797,7 +816,7 @@ int orc_uqmpc_step(orc_ctx* c, int64_t batch, int uq_update, const double* x, co
                           alpha ? alpha + b : NULL, v ? v + b * nx : NULL, hk ? hk + b * c->nc : NULL,
                           Sb_hat ? Sb_hat + b * c->nS : NULL, Wb_hat ? Wb_hat + b * c->nW : NULL,
                           n_active ? n_active + b : NULL, active_set ? active_set + b * LBMPC_MAX_NZ : NULL,
-                          qp_iters ? qp_iters + b : NULL);
+                          qp_iters ? qp_iters + b : NULL, NULL, NULL);
         if (status) status[b] = st;
     }
     return 0;
@@ -811,6 +830,7 @@ int orc_mc_run(orc_ctx* c, const lbmpc_sampler* smp, const lbmpc_mc_cfg* cfg, lb
     for (int64_t t = 0; t < cfg->trials; ++t) {
         uint64_t tid = (uint64_t)(cfg->trial0 + t);
         int status = 0, infeasible = 0, iters_total = 0;
+        int hint[LBMPC_MAX_NZ], nhint = 0; /* active set of the previous step's QP (pivot candidates) */
         /* initial set learning: InitialSetComputation.solve (:48-59) */
         double m[LBMPC_MAX_NW], alpha, v[LBMPC_MAX_NX];
         for (int j = 0; j < nW; ++j) m[j] = -INFINITY;
@@ -846,7 +866,7 @@ int orc_mc_run(orc_ctx* c, const lbmpc_sampler* smp, const lbmpc_mc_cfg* cfg, lb
             }
             double s0[LBMPC_MAX_NX], u[LBMPC_MAX_NZ], a2, v2[LBMPC_MAX_NX];
             int it = 0;
-            st = step_one(c, 1, x, alpha, v, w_new, s0, NULL, u, &a2, v2, NULL, NULL, NULL, NULL, NULL, &it);
+            st = step_one(c, 1, x, alpha, v, w_new, s0, NULL, u, &a2, v2, NULL, NULL, NULL, NULL, NULL, &it, hint, &nhint);
             if (st > status) status = st;
             iters_total += it;
             alpha = a2; memcpy(v, v2, sizeof(double) * nx);
