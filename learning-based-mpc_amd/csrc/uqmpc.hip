@@ -112,7 +112,8 @@ __device__ __forceinline__ void w_hat_b(const CtxDev* __restrict__ C, double alp
 // Online set update LPforUQ (UQRobustMPC.m:124-139): homothety LP on m = max(b_hat_prev, W_A w_new);
 // (alpha, v) unchanged when w_new is inside W_hat_prev.
 template <int NX>
-__device__ __forceinline__ int uq_update(const CtxDev* __restrict__ C, double& alpha, double* v, const double* w, double* bh) {
+__device__ __forceinline__ int uq_update(const CtxDev* __restrict__ C, double& alpha, double* v, const double* w, double* bh,
+                                         bool* changed = nullptr) {
     double mm[2 * NX];
     bool outside = false;
     int st = 0;
@@ -130,6 +131,7 @@ __device__ __forceinline__ int uq_update(const CtxDev* __restrict__ C, double& a
         st = homothety_box<NX>(&C->box, mm, alpha, v, mask);
         w_hat_b<NX>(C, alpha, v, bh);
     }
+    if (changed) *changed = outside;
     return st;
 }
 
@@ -144,6 +146,28 @@ __device__ __forceinline__ void tighten(const CtxDev* __restrict__ C, double alp
 #pragma unroll
         for (int k = 0; k < NX; ++k) acc = fma(C->T[i * NX + k], v[k], acc);
         q[i] = beta * acc - x[i];
+    }
+    min_omh = LB_INF; arg_omh = 0;
+    for (int r = 0; r < C->nc; ++r) {
+        double g = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) g = fma(C->FcT[r * NX + k], v[k], g);
+        double omh = 1.0 - (alpha * C->hs[r] + beta * g);
+        if (omh < min_omh) { min_omh = omh; arg_omh = r; }
+    }
+}
+
+// the part of tighten() that depends on (alpha, v) only: bTv = (1-alpha) T v, min_r (1 - h_k[r]) and its index
+template <int NX>
+__device__ __forceinline__ void tighten_set(const CtxDev* __restrict__ C, double alpha, const double* v, double* bTv,
+                                            double& min_omh, int& arg_omh) {
+    const double beta = 1.0 - alpha;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) acc = fma(C->T[i * NX + k], v[k], acc);
+        bTv[i] = beta * acc;
     }
     min_omh = LB_INF; arg_omh = 0;
     for (int r = 0; r < C->nc; ++r) {
@@ -583,6 +607,8 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
         double x[T][NX], wst[T][NX], v[T][NX], alpha[T];
         int status[T], infeasible[T], iters[T];
         bool hashint[T];   // the trial's candidate list in HBM is non-empty
+        bool stale[T];     // bTv / momh_c must be recomputed
+        double bTv[T][NX], momh_c[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int64_t l = base + t * LB_WAVE + lane;
@@ -590,7 +616,9 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
             cl[t] = valid[t] ? l : a.chunk_n - 1;
             tl[t] = a.chunk0 + cl[t];
             tid[t] = (uint64_t)(a.trial0 + tl[t]);
-            status[t] = a.steps > 0 ? a.xi_status[cl[t]] : 0; infeasible[t] = 0; iters[t] = 0; hashint[t] = false;
+            status[t] = a.steps > 0 ? a.xi_status[cl[t]] : 0; infeasible[t] = 0; iters[t] = 0; hashint[t] = false; stale[t] = true; momh_c[t] = 0.0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) bTv[t][i] = 0.0;
             // initial set learning: InitialSetComputation.solve (:48-59), card_I0 samples
             double m[2 * NX];
 #pragma unroll
@@ -637,10 +665,18 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
                 // LVModeling first (Case_3...:58; ModelingCar.m:42-43): xi_LV, xi_EV come from the pre-pass
                 PROF_T(pa);
                 double bh[2 * NX];
-                int st = uq_update<NX>(C, alpha[t], v[t], wst[t], bh);  // w_new = 0 at k = 0 (Case_3...:62-65)
+                bool changed = false;
+                int st = uq_update<NX>(C, alpha[t], v[t], wst[t], bh, &changed);  // w_new = 0 at k = 0 (Case_3...:62-65)
                 status[t] = st > status[t] ? st : status[t];
                 PROF_T(pb);
-                tighten<NX>(C, alpha[t], v[t], x[t], q[t], momh[t], aomh[t]);
+                // (1-alpha) T v and min(1 - h_k) only move when the set update moved (alpha, v): kept between steps
+                if (__builtin_amdgcn_ballot_w64(changed || stale[t]) != 0) {
+                    tighten_set<NX>(C, alpha[t], v[t], bTv[t], momh_c[t], aomh[t]);
+                    stale[t] = false;
+                }
+                momh[t] = momh_c[t];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) q[t][i] = bTv[t][i] - x[t][i];
                 PROF_T(pc);
                 PROF_ADD(16, p0, pa); PROF_ADD(17, pa, pb); PROF_ADD(18, pb, pc);
             }
@@ -703,6 +739,9 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
                         tl[tt] = __double_as_longlong(pk[(slot++) * ps]);
                         cl[tt] = __double_as_longlong(pk[(slot++) * ps]);
                         tid[tt] = (uint64_t)__double_as_longlong(pk[(slot++) * ps]);
+                        stale[tt] = true; momh_c[tt] = 0.0;   // not kept across the solve: recomputed at the next step
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) bTv[tt][i] = 0.0;
                     }
                 }
                 // no QP this step = the oracle's trivial solve with an empty active set: no candidates next step
