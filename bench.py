@@ -96,22 +96,25 @@ def main():
     total_steps = args.trials * world * args.horizon * args.steps
     value = total_steps / dt
     iters_local = int(bufs.qp_iters.sum().item())
-    # ALGORITHMIC flops of one launch on this GPU (DESIGN.md "Kernel 3", the figure roofline.achieved uses): one pass
-    # over the nS rows of S_hat per MPC step (2 nS nx) + one full constraint pass (2 (nS nx + nH nz)) per active-set
-    # iteration.  The kernel does NOT execute most of the per-step pass: an inscribed-ellipsoid test proves it empty.
-    flops = args.trials * args.horizon * 2.0 * nS * nx + iters_local * 2.0 * (nS * nx + nH * nz)
-    achieved = flops / (kern_ms * 1e-3) / 1e12
-    # arithmetic that was actually executed, from the library's work counters
+    # ALGORITHMIC flops of one launch on this GPU = the arithmetic the design executes, from the library's work counters
+    # (DESIGN.md "Kernel 3"): per MPC step the set update, tightening, ellipsoid test and plant update; per filtered
+    # wave-step one fp32 pass over the S rows for 64 trials; per full pivot scan one fp64 pass over the S rows for 4 QPs
+    # (+ one pass over the H rows for 2 QPs where the certificate does not skip it); per solver trip the O(nz^2) algebra.
     cnt = ctx.mc_counters()
     nu_ = int(P["nu"]); nc_ = int(P["nc"])
     per_step64 = 2.0 * (nx * nx + nx) + 2.0 * nx * nx + 2.0 * nc_ * nx + 8.0 * nx * nx + 2.0 * nx * nx + 4.0 * nx * nu_
     exec64 = (args.trials * args.horizon * per_step64
-              + cnt["pivot_scans"] * 4.0 * 2.0 * ((nx + 1) * nS + nz * nH)
+              + cnt["pivot_scans"] * 4.0 * 2.0 * (nx + 1) * nS + cnt["h_passes"] * 2.0 * 2.0 * nz * nH
               + cnt["solver_trips"] * 4.0 * 6.0 * nz * nz)
     exec32 = cnt["filter_wave_steps"] * 64.0 * 2.0 * (nx + 1) * nS
-    executed = {"fp64_flops_per_launch": exec64, "fp32_flops_per_launch": exec32,
-                "fp64_tflops": exec64 / (kern_ms * 1e-3) / 1e12, "frac_of_fp64_peak": exec64 / (kern_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                "counters": cnt}
+    flops = exec64
+    achieved = flops / (kern_ms * 1e-3) / 1e12
+    # what a solver without the pruning (one S pass per step + one full pass per active-set iteration) would
+    # have to execute for the same results: reported for scale only, NOT a roofline position
+    naive = args.trials * args.horizon * 2.0 * nS * nx + iters_local * 2.0 * (nS * nx + nH * nz)
+    executed = {"fp64_flops_per_launch": exec64, "fp32_flops_per_launch": exec32, "counters": cnt,
+                "unpruned_equivalent_flops_per_launch": naive,
+                "unpruned_equivalent_tflops": naive / (kern_ms * 1e-3) / 1e12}
 
     # ---------------------------------------------------------------- secondary leg: set learning (C2)
     P2 = params.load(os.path.join(ROOT, "tests", "golden", "params_2x2.npz"))
@@ -226,10 +229,11 @@ def main():
             "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic_mc, "kernel": "mc_kernel (+ mc_sample_kernel pre-pass)",
                          "kernel_ms": kern_ms, "algorithmic_flops_per_launch": flops, "executed": executed,
-                         "note": "MFMA deliberately unused (north_star); bound is the fp64 vector rate. achieved prices the "
-                                 "algorithmic flops (one S pass per step + one full pass per active-set iteration); the kernels "
-                                 "(mc_sample_kernel + mc_kernel, timed together) skip provably empty passes, so the arithmetic "
-                                 "really executed is the much smaller figure under 'executed'"},
+                         "note": "MFMA deliberately unused (north_star); bound is the fp64 vector rate. achieved prices the fp64 "
+                                 "arithmetic the two kernels (mc_sample_kernel + mc_kernel, timed together) execute, counted by "
+                                 "the library's work counters; the path is instruction-issue/latency bound (DESIGN.md), most "
+                                 "instructions are bookkeeping, not flops. 'unpruned_equivalent' is what a solver without the "
+                                 "exact pruning (ellipsoid test, H-row certificate, candidate pivots) would execute"},
             "set_learning": {"value": sl_value, "unit": "samples/s", "ms_per_step": sl_ms,
                              "config": {"workload": f"C2: 2x2 set learning, {B} information sets/GPU x {N} samples resident in HBM"},
                              "roofline": {"bound": "hbm", "achieved": sl_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -261,7 +261,7 @@ int lbmpc_mc_run_dev(lbmpc_ctx* ctx, const lbmpc_sampler* smp, const lbmpc_mc_cf
  * counterpart in the reference (its loops are timed with tic/toc, Case_3...:57,69); used by bench.py to state the
  * arithmetic that was actually executed.  out[0] wave-steps whose rows were scanned by the fp32 filter (64 trials
  * each), out[1] wave-steps in total, out[2] QP solves, out[3] solver rounds (up to 4 QPs each), out[4] solver loop
- * trips, out[5] pivot scans (4 QPs each), out[6..7] reserved. */
+ * trips, out[5] full pivot scans (4 QPs each), out[6] passes over the H rows inside them (2 QPs each), out[7] reserved. */
 int lbmpc_mc_counters(lbmpc_ctx* ctx, uint64_t* out8);
 
 #ifdef __cplusplus

@@ -107,7 +107,7 @@ __device__ __forceinline__ void mark_rows(bool flag, int p, int nS, int lane, ui
 template <int NX>
 __device__ __forceinline__ void scan_rows(const CtxDev* __restrict__ C, const LdsView& L, const double* wws,
                                           double alpha, const double* q, double my_z, bool need, const uint32_t* actS,
-                                          const uint32_t* actH, double& best_out, int& bj_out) {
+                                          const uint32_t* actH, double& best_out, int& bj_out, unsigned* hpasses) {
     constexpr int RLc = NX + 1;
     const int lane = lane_id(), grp = lane >> 4;
     const int nS = C->nS, nH = C->nH, nc = C->nc, nzp = C->nzp, nz = C->nz;
@@ -174,6 +174,7 @@ __device__ __forceinline__ void scan_rows(const CtxDev* __restrict__ C, const Ld
 #pragma unroll
         for (int g0 = 0; g0 < 4; g0 += 2) {
             if (__builtin_amdgcn_readlane((int)hskip, 16 * g0) && __builtin_amdgcn_readlane((int)hskip, 16 * (g0 + 1))) continue;
+            *hpasses += 1;
             double zu[2][NZMAX];
 #pragma unroll
             for (int gg = 0; gg < 2; ++gg)
@@ -341,7 +342,7 @@ __device__ __forceinline__ void chol_append_row(const CtxDev* __restrict__ C, co
 // gws: this ROW's LDS slot (omh filled by the caller; results written at the end).
 template <int NX>
 __device__ __forceinline__ void group_qp_solve(const CtxDev* __restrict__ C, const LdsView& L, double* gws, bool live,
-                                               double alpha, const double* q, unsigned* ctr /* [0] trips, [1] scans (wave-uniform) */,
+                                               double alpha, const double* q, unsigned* ctr /* [0] trips, [1] full scans, [2] H passes (wave-uniform) */,
                                                int* hint_rows /* this row's 16 candidate slots in HBM, or null */,
                                                int* hint_n /* their count (in: previous step, out: this solve) */,
                                                long long* prof = nullptr) {
@@ -402,7 +403,7 @@ __device__ __forceinline__ void group_qp_solve(const CtxDev* __restrict__ C, con
                 ctr[1] += 1;
                 double fb = -QP_TOL_VIOL;
                 int fj = 0x7fffffff;
-                scan_rows<NX>(C, L, gws - grp * GWS_DOUBLES, alpha, q, my_z, need_full, actS, actH, fb, fj);
+                scan_rows<NX>(C, L, gws - grp * GWS_DOUBLES, alpha, q, my_z, need_full, actS, actH, fb, fj, ctr + 2);
                 if (need_full) { best = fb; bj = fj; }
             }
             const bool optimal = need_scan && bj == 0x7fffffff;

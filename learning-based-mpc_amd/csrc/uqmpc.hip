@@ -307,7 +307,7 @@ __device__ __forceinline__ void solve_flagged(const CtxDev* __restrict__ C, cons
                                               bool need, double alpha, const double* v, const double* q,
                                               double* s0, double* c0, int& status, int& iters,
                                               int* nact_out, int* act_out /* NZMAX, sorted, or null */,
-                                              double* c_full /* nz-NX or null */, unsigned* ctr /* [0] solves [1] rounds [2] trips [3] scans */,
+                                              double* c_full /* nz-NX or null */, unsigned* ctr /* [0] solves [1] rounds [2] trips [3] scans [4] H passes */,
                                               int* hint_base /* [chunk trial][16] pivot candidates in HBM, or null */,
                                               int* nhint_base /* [chunk trial] */, int cl /* this lane's chunk trial */,
                                               long long* prof = nullptr) {
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void uqmpc_step_kernel(const CtxDev* __restric
         double* cdst = (valid && io.c) ? io.c + b * ncv : nullptr;
         if (cdst) for (int k = 0; k < ncv; ++k) cdst[k] = 0.0;
         if (valid && io.active_set) for (int a = 0; a < NZMAX; ++a) io.active_set[b * NZMAX + a] = -1;
-        unsigned ctr[4] = {0, 0, 0, 0};
+        unsigned ctr[5] = {0, 0, 0, 0, 0};
         solve_flagged<NX>(C, L, ws, valid && need[0], alpha[0], v, q[0], s0, c0, status, iters,
                           &nact, (valid && io.active_set) ? io.active_set + b * NZMAX : nullptr, cdst, ctr, nullptr, nullptr, 0);
         (void)act_sorted;
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
     const int nz = C->nz, nu = C->nu, K = a.steps;
     double* ws = ws_base + wave * ws_doubles(nz);
     const SamplerDev* S = &smp;
-    unsigned ctr[6] = {0, 0, 0, 0, 0, 0};  // wave-uniform work counters (lbmpc_mc_counters)
+    unsigned ctr[7] = {0, 0, 0, 0, 0, 0, 0};  // wave-uniform work counters (lbmpc_mc_counters)
 #ifdef LBMPC_PROFILE
     long long prof[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     PROF_T(pk0);
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
         }
     }
     if (lane == 0 && a.counters)
-        for (int i = 0; i < 6; ++i) atomicAdd(a.counters + i, (unsigned long long)ctr[i]);
+        for (int i = 0; i < 7; ++i) atomicAdd(a.counters + i, (unsigned long long)ctr[i]);
 #ifdef LBMPC_PROFILE
     PROF_T(pk1);
     prof[6] = pk1 - pk0;
