@@ -397,3 +397,14 @@ def test_mc_oriented_proposal_vs_oracle(core, system, x0):
     assert np.all(np.abs(sa.mean(1) - sb.mean(1)) < 5 * sd / np.sqrt(N) * 1.5)
     assert np.allclose(np.cov(sa), np.cov(sb), rtol=0.06, atol=0.02 * sd.max() ** 2)
     ctx.close(); octx.close()
+
+
+@pytest.mark.parametrize("trials,steps", [(1, 0), (1, 1), (3, 2), (65, 3), (130, 5)])
+def test_mc_tiny_shapes_vs_oracle(core, P, smp, trials, steps):
+    """edge shapes of the closed-loop launch: no steps at all, fewer steps than a store group of the pre-pass,
+    fewer trials than a 4-trial sampling group / a wave, ragged last wave"""
+    ctx, octx = core.Context(P), oracle_core.Context(P)
+    kw = dict(trials=trials, steps=steps, card_I0=7, seed=21, x0=[-12.0, 5.0], acc_bound=2.0, distance_error=15.0,
+              traj_trials=trials)
+    compare_mc(ctx.mc_run(smp, **kw), octx.mc_run(smp, **kw))
+    ctx.close(); octx.close()
