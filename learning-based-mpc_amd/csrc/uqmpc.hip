@@ -655,7 +655,11 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
                 const double* xl = a.xi + xi_index<NX>(0, cl[t], k, K, a.chunk_n);
                 const double* xe = a.xi + xi_index<NX>(1, cl[t], k, K, a.chunk_n);
 #pragma unroll
+#ifdef LBMPC_ABLATE_XI_LOAD
+                for (int i = 0; i < NX; ++i) { xi_lv[t][i] = 1e-3 * (double)((tid[t] + k + i) & 7); xi_ev[t][i] = 1e-3 * (double)((tid[t] + 3 * k + i) & 7); (void)xl; (void)xe; }
+#else
                 for (int i = 0; i < NX; ++i) { xi_lv[t][i] = xl[i]; xi_ev[t][i] = xe[i]; }
+#endif
             }
             int aomh[T];
             bool need[T];
