@@ -462,6 +462,7 @@ struct McArgs {
     double x0[LBMPC_MAX_NX];
     double acc_bound, distance_error;
     int traj_trials, sampler_max_attempts;
+    int tpw;  // trials per wave (and per t): 4 .. 64
     // this launch covers local trials [chunk0, chunk0 + chunk_n); xi holds their pre-drawn step disturbances
     int64_t chunk0, chunk_n;
     const double* xi;       // pre-drawn xi_LV / xi_EV, layout xi_index()
@@ -599,8 +600,11 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
     long long prof[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     PROF_T(pk0);
 #endif
-    for (int64_t base = ((int64_t)blockIdx.x * nwaves + wave) * (LB_WAVE * T); base < a.chunk_n;
-         base += (int64_t)gridDim.x * nwaves * (LB_WAVE * T)) {
+    // a.tpw trials per wave and per t (64 for large batches; fewer lanes per wave for small ones, so that the solver
+    // rounds of a step -- 4 QPs at a time -- spread over more waves)
+    const int tpw = a.tpw;
+    for (int64_t base = ((int64_t)blockIdx.x * nwaves + wave) * (tpw * T); base < a.chunk_n;
+         base += (int64_t)gridDim.x * nwaves * (tpw * T)) {
         int64_t tl[T], cl[T];  // local trial index (output arrays), index inside this chunk (xi)
         uint64_t tid[T];    // global id = RNG stream key
         bool valid[T];
@@ -611,8 +615,8 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
         double bTv[T][NX], momh_c[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            const int64_t l = base + t * LB_WAVE + lane;
-            valid[t] = l < a.chunk_n;
+            const int64_t l = base + t * tpw + lane;
+            valid[t] = lane < tpw && l < a.chunk_n;
             cl[t] = valid[t] ? l : a.chunk_n - 1;
             tl[t] = a.chunk0 + cl[t];
             tid[t] = (uint64_t)(a.trial0 + tl[t]);
@@ -1125,7 +1129,13 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
     const int waves = pick_waves(c, 8);
     if (!waves) { set_error("constants (%zu B) do not fit in LDS", c->lds_const_bytes); return LBMPC_ERR_DIM; }
     const size_t lds = c->lds_const_bytes + (size_t)waves * ws_doubles(c->h.nz) * 8;
-    const int per_block = waves * 64 * (wide ? 2 : 1);
+    // trials per wave: 64 once that still gives every SIMD two waves, else fewer lanes per wave (down to one solver
+    // round of 4 QPs per step) so that small batches spread over the chip
+    int tpw = 64;
+    while (tpw > 4 && (cfg->trials + tpw - 1) / tpw < 2048) tpw >>= 1;
+    if (const char* env_w = getenv("LBMPC_MC_TPW")) { const int v = atoi(env_w); if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) tpw = v; }
+    a.tpw = tpw;
+    const int per_block = waves * tpw * (wide ? 2 : 1);
     // trial chunks: the pre-drawn disturbances of one chunk take steps * 2 nx * 8 B per trial
     const size_t per_trial = xi_bytes_for(c->h.nx, cfg->steps, 64) / 64;
     const char* env_g = getenv("LBMPC_MC_XI_GIB");

@@ -326,7 +326,8 @@ def test_mc_generated_systems_vs_oracle(core, system, x0, steps):
     compare_mc(g, o)
     assert o["qp_iters"].min() > 0
     cnt = ctx.mc_counters()
-    assert cnt["wave_steps"] == 4 * steps and cnt["qp_solves"] > 0 and cnt["pivot_scans"] >= cnt["solver_rounds"] > 0
+    assert cnt["wave_steps"] % steps == 0 and cnt["wave_steps"] >= 4 * steps   # 200 trials in waves of 4 .. 64
+    assert cnt["qp_solves"] > 0 and cnt["pivot_scans"] >= cnt["solver_rounds"] > 0
     assert 0 < cnt["filter_wave_steps"] < cnt["wave_steps"]   # transient scanned, steady state skipped
     ctx.close(); octx.close()
 
@@ -408,3 +409,21 @@ def test_mc_tiny_shapes_vs_oracle(core, P, smp, trials, steps):
               traj_trials=trials)
     compare_mc(ctx.mc_run(smp, **kw), octx.mc_run(smp, **kw))
     ctx.close(); octx.close()
+
+
+def test_mc_trials_per_wave_invariance(core, P, smp):
+    """small batches run with fewer trials per wave (4 .. 32 lanes) so that the solver rounds spread over more waves;
+    every packing gives bitwise the same results (LBMPC_MC_TPW forces one)"""
+    import os
+    ctx = core.Context(P)
+    kw = dict(trials=700, steps=9, card_I0=10, seed=13, x0=[-12.0, 5.0], acc_bound=2.0, distance_error=15.0, traj_trials=700)
+    ref = ctx.mc_run(smp, **kw)          # automatic choice (4 per wave at this size)
+    try:
+        for tpw in ("8", "32", "64"):
+            os.environ["LBMPC_MC_TPW"] = tpw
+            got = ctx.mc_run(smp, **kw)
+            for k in ref:
+                np.testing.assert_array_equal(ref[k], got[k], err_msg=f"{k} tpw={tpw}")
+    finally:
+        os.environ.pop("LBMPC_MC_TPW", None)
+    ctx.close()

@@ -1,0 +1,29 @@
+"""Throughput of the other BASELINE configurations (C1 2x2 Case_3 style, C3 3x3 Case_5 style) -- informational."""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "learning-based-mpc_amd"))
+from lbmpc import core, dev, params
+device = torch.device("cuda:0")
+for name, P, x0, trials, steps, card in (
+        ("C1 2x2", params.load(os.path.join(ROOT, "tests", "golden", "params_2x2.npz")), [-12.0, 5.0], 65536, 50, 100),
+        ("C3 3x3", params.load("3x3"), [-12.0, 5.0, 0.0], 10000, 20, 10),
+        ("C4 4x4 short", params.load("4x4"), [-12.0, 5.0, 0.0, 0.0], 131072, 50, 10)):
+    ctx = core.Context(P)
+    for oriented in (False, True):
+        smp = params.sampler(P, oriented=oriented)
+        bufs = dev.McBuffers(ctx, trials, device)
+        kw = dict(steps=steps, card_I0=card, seed=1, x0=np.array(x0), acc_bound=float(np.ravel(P["acc_bound"])[0]),
+                  distance_error=float(np.ravel(P["distance_error"])[0]), trial0=0)
+        for _ in range(2):
+            dev.mc_run(ctx, smp, bufs, **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            dev.mc_run(ctx, smp, bufs, **kw)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 5
+        print(f"{name}: {trials} trials x {steps} steps, card(I0)={card}, oriented={oriented}: {dt*1e3:.2f} ms/launch, "
+              f"{trials*steps/dt:.3e} steps/s, iters/trial {bufs.qp_iters.float().mean().item():.1f}, "
+              f"infeasible {int(bufs.infeasible.sum().item())}, max status {int(bufs.status.max().item())}")
+    ctx.close()
