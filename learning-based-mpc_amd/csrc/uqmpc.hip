@@ -221,9 +221,34 @@ __device__ __forceinline__ void first_pass_eval(const float4* cur, const float* 
 // the fp32 minimum is below -tol + margin, margin = 2^-20 (alpha max|S_b| + sum_k max|S_A[:,k]| |q_k|) >= twice the
 // worst-case rounding error (gamma_7, u = 2^-24) of any row.  A violated row is therefore never missed; a false
 // alarm costs one scan.  NaN / overflow compare as "flagged".
+// Ellipsoid early-out of the first pass: outside[t] = the trial is NOT proven free of violated S rows.
 template <int NX, int T>
-__device__ __forceinline__ bool first_pass(const CtxDev* __restrict__ C, const LdsView& L, const double* alpha,
-                                           const double (*q)[NX], const double* min_omh, bool* need) {
+__device__ __forceinline__ bool ellipsoid_outside(const CtxDev* __restrict__ C, const double* alpha, const double (*q)[NX],
+                                                  bool* outside) {
+    bool any = false;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        double e2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            double ti = 0.0;
+#pragma unroll
+            for (int k = 0; k < NX; ++k) ti = fma(C->ME[i * NX + k], q[t][k], ti);
+            e2 = fma(q[t][i], ti, e2);
+        }
+        const double as = alpha[t] * (1.0 - 1e-6);
+        // slack_j >= alpha 1e-6 b_j must clear the tolerance and the rounding of the exact evaluation
+        const bool inside = C->hasE && alpha[t] * 1e-6 * C->bmin >= 1e-9 && e2 <= as * as;
+        outside[t] = !inside;
+        any = any || !inside;
+    }
+    return any;
+}
+
+// Packed-fp32 scan of the S rows (second stage of the first-pass filter): need[t] = some row may be violated.
+template <int NX, int T>
+__device__ __forceinline__ void filter_scan(const CtxDev* __restrict__ C, const LdsView& L, const double* alpha,
+                                            const double (*q)[NX], bool* need) {
     constexpr int RLc = NX + 1;
     constexpr int CH = 2 * RLc;
     float mn[T], af[T], qf[T][NX];
@@ -236,30 +261,6 @@ __device__ __forceinline__ bool first_pass(const CtxDev* __restrict__ C, const L
 #pragma unroll
         for (int k = 0; k < NX; ++k) { qf[t][k] = (float)q[t][k]; e = fma(C->amax[k], fabs(q[t][k]), e); }
         thresh[t] = -QP_TOL_VIOL + 0x1p-20 * e;
-    }
-    // ellipsoid early-out: when every trial of the wave lies inside alpha (1-1e-6) E there is nothing to scan
-    {
-        bool outside = false;
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            double e2 = 0.0;
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                double ti = 0.0;
-#pragma unroll
-                for (int k = 0; k < NX; ++k) ti = fma(C->ME[i * NX + k], q[t][k], ti);
-                e2 = fma(q[t][i], ti, e2);
-            }
-            const double as = alpha[t] * (1.0 - 1e-6);
-            // slack_j >= alpha 1e-6 b_j must clear the tolerance and the rounding of the exact evaluation
-            const bool inside = C->hasE && alpha[t] * 1e-6 * C->bmin >= 1e-9 && e2 <= as * as;
-            outside = outside || !inside;
-        }
-        if (__builtin_amdgcn_ballot_w64(outside) == 0) {
-#pragma unroll
-            for (int t = 0; t < T; ++t) need[t] = min_omh[t] < -QP_TOL_VIOL;
-            return false;
-        }
     }
     const int nch = C->nSp >> 3;       // chunks of 8 rows; even: nSp is a multiple of 128
     const float4* p = reinterpret_cast<const float4*>(L.S32);
@@ -280,8 +281,24 @@ __device__ __forceinline__ bool first_pass(const CtxDev* __restrict__ C, const L
         first_pass_eval<NX, T>(bufB, af, qf, mn);
     }
 #pragma unroll
-    for (int t = 0; t < T; ++t) need[t] = (min_omh[t] < -QP_TOL_VIOL) || !((double)mn[t] >= thresh[t]);
-    return true;  // the rows were scanned
+    for (int t = 0; t < T; ++t) need[t] = !((double)mn[t] >= thresh[t]);
+}
+
+template <int NX, int T>
+__device__ __forceinline__ bool first_pass(const CtxDev* __restrict__ C, const LdsView& L, const double* alpha,
+                                           const double (*q)[NX], const double* min_omh, bool* need) {
+    bool outside[T];
+    const bool any = ellipsoid_outside<NX, T>(C, alpha, q, outside);
+    bool scanned = false;
+#pragma unroll
+    for (int t = 0; t < T; ++t) need[t] = false;
+    if (__builtin_amdgcn_ballot_w64(any) != 0) {
+        filter_scan<NX, T>(C, L, alpha, q, need);
+        scanned = true;
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) need[t] = need[t] || (min_omh[t] < -QP_TOL_VIOL);
+    return scanned;  // the rows were scanned
 }
 
 // Copies the constants into LDS and returns the view; *ws_base = first per-wave solver slot.
@@ -689,80 +706,108 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
                 PROF_ADD(16, p0, pa); PROF_ADD(17, pa, pb); PROF_ADD(18, pb, pc);
             }
             PROF_T(p1);
-            ctr[0] += first_pass<NX, T>(C, L, alpha, q, momh, need) ? T : 0;
+            // first pass, stage 1 (per step, cheap): ellipsoid test; the H rows contribute min(1 - h_k) exactly
+            bool outside[T];
+            bool heavy = ellipsoid_outside<NX, T>(C, alpha, q, outside);
+            double s0[T][NX], c0[T][LBMPC_MAX_NU];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                need[t] = momh[t] < -QP_TOL_VIOL;
+                heavy = heavy || need[t];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) s0[t][i] = 0.0;
+#pragma unroll
+                for (int j = 0; j < LBMPC_MAX_NU; ++j) c0[t][j] = 0.0;
+            }
             ctr[1] += T;
             PROF_T(p2);
             PROF_ADD(0, p0, p1); PROF_ADD(1, p1, p2);
+            PROF_T(p3);
+            if (__builtin_amdgcn_ballot_w64(heavy) != 0) {
+                // Entered in ~1 % of the steps of a long horizon: row filter and QP solves.  The closed-loop state is
+                // parked in HBM for the duration (and read back through a laundered pointer, so that the values
+                // are new ones): otherwise the register peak of this region makes the allocator spill that state on
+                // the steady-state path of EVERY step (14.7 GB of scratch writes per C4 launch before this).
+                double* pk = a.park + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+                const int64_t ps = (int64_t)gridDim.x * blockDim.x;
+                int slot = 0;
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-                double s0[NX], c0[LBMPC_MAX_NU], u[LBMPC_MAX_NU];
+                for (int tt = 0; tt < T; ++tt) {
 #pragma unroll
-                for (int i = 0; i < NX; ++i) s0[i] = 0.0;
-#pragma unroll
-                for (int j = 0; j < LBMPC_MAX_NU; ++j) c0[j] = 0.0;
-                PROF_T(p3);
-#ifdef LBMPC_PROFILE
-                prof[4] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid[t] && need[t]));
-                prof[5] += (__builtin_popcountll(__builtin_amdgcn_ballot_w64(valid[t] && need[t])) + 3) >> 2;
-#endif
-                if (__builtin_amdgcn_ballot_w64(valid[t] && need[t]) != 0) {
-                    // Entered in ~1 % of the steps of a long horizon.  The closed-loop state is parked in HBM for
-                    // the duration of the solve (and read back through a laundered pointer, so that the values are
-                    // new ones): otherwise the solver's register peak makes the allocator spill that state on the
-                    // steady-state path of EVERY step (14.7 GB of scratch writes per C4 launch before this).
-                    double* pk = a.park + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
-                    const int64_t ps = (int64_t)gridDim.x * blockDim.x;
-                    int slot = 0;
-#pragma unroll
-                    for (int tt = 0; tt < T; ++tt) {
-#pragma unroll
-                        for (int i = 0; i < NX; ++i) {
-                            pk[(slot++) * ps] = x[tt][i]; pk[(slot++) * ps] = v[tt][i];
-                            pk[(slot++) * ps] = xi_lv[tt][i]; pk[(slot++) * ps] = xi_ev[tt][i];
-                        }
-                        pk[(slot++) * ps] = alpha[tt];
-                        pk[(slot++) * ps] = __longlong_as_double(tl[tt]);
-                        pk[(slot++) * ps] = __longlong_as_double(cl[tt]);
-                        pk[(slot++) * ps] = __longlong_as_double((long long)tid[tt]);
+                    for (int i = 0; i < NX; ++i) {
+                        pk[(slot++) * ps] = x[tt][i]; pk[(slot++) * ps] = v[tt][i];
+                        pk[(slot++) * ps] = xi_lv[tt][i]; pk[(slot++) * ps] = xi_ev[tt][i];
                     }
-                    const double a_t = alpha[t];
-                    double v_t[NX], q_t[NX];
+                    pk[(slot++) * ps] = alpha[tt];
+                    pk[(slot++) * ps] = __longlong_as_double(tl[tt]);
+                    pk[(slot++) * ps] = __longlong_as_double(cl[tt]);
+                    pk[(slot++) * ps] = __longlong_as_double((long long)tid[tt]);
+                }
+                double a_c[T], v_c[T][NX], q_c[T][NX];
+                int cl_c[T];
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) { v_t[i] = v[t][i]; q_t[i] = q[t][i]; }
-                    int nact_t = 0;
-                    solve_flagged<NX>(C, L, ws, valid[t] && need[t], a_t, v_t, q_t, s0, c0,
-                                      status[t], iters[t], &nact_t, nullptr, nullptr, ctr + 2, a.hint, a.nhint,
-                                      (int)cl[t], PROF_PTR);
-                    if (valid[t] && need[t]) hashint[t] = nact_t > 0;
-                    asm volatile("" : "+v"(pk));
-                    slot = 0;
+                for (int t = 0; t < T; ++t) {
+                    a_c[t] = alpha[t]; cl_c[t] = (int)cl[t];
 #pragma unroll
-                    for (int tt = 0; tt < T; ++tt) {
+                    for (int i = 0; i < NX; ++i) { v_c[t][i] = v[t][i]; q_c[t][i] = q[t][i]; }
+                }
+                // stage 2: packed-fp32 scan of the S rows when some trial is outside the ellipsoid
+                bool anyout = false;
 #pragma unroll
-                        for (int i = 0; i < NX; ++i) {
-                            x[tt][i] = pk[(slot++) * ps]; v[tt][i] = pk[(slot++) * ps];
-                            xi_lv[tt][i] = pk[(slot++) * ps]; xi_ev[tt][i] = pk[(slot++) * ps];
-                        }
-                        alpha[tt] = pk[(slot++) * ps];
-                        tl[tt] = __double_as_longlong(pk[(slot++) * ps]);
-                        cl[tt] = __double_as_longlong(pk[(slot++) * ps]);
-                        tid[tt] = (uint64_t)__double_as_longlong(pk[(slot++) * ps]);
-                        stale[tt] = true; momh_c[tt] = 0.0;   // not kept across the solve: recomputed at the next step
+                for (int t = 0; t < T; ++t) anyout = anyout || outside[t];
+                if (__builtin_amdgcn_ballot_w64(anyout) != 0) {
+                    bool nf[T];
+                    filter_scan<NX, T>(C, L, a_c, q_c, nf);
 #pragma unroll
-                        for (int i = 0; i < NX; ++i) bTv[tt][i] = 0.0;
+                    for (int t = 0; t < T; ++t) need[t] = need[t] || nf[t];
+                    ctr[0] += T;
+                }
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const bool nd = valid[t] && need[t];
+#ifdef LBMPC_PROFILE
+                    prof[4] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(nd));
+                    prof[5] += (__builtin_popcountll(__builtin_amdgcn_ballot_w64(nd)) + 3) >> 2;
+#endif
+                    if (__builtin_amdgcn_ballot_w64(nd) != 0) {
+                        int nact_t = 0;
+                        solve_flagged<NX>(C, L, ws, nd, a_c[t], v_c[t], q_c[t], s0[t], c0[t], status[t], iters[t],
+                                          &nact_t, nullptr, nullptr, ctr + 2, a.hint, a.nhint, cl_c[t], PROF_PTR);
+                        if (nd) hashint[t] = nact_t > 0;
                     }
                 }
+                asm volatile("" : "+v"(pk));
+                slot = 0;
+#pragma unroll
+                for (int tt = 0; tt < T; ++tt) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) {
+                        x[tt][i] = pk[(slot++) * ps]; v[tt][i] = pk[(slot++) * ps];
+                        xi_lv[tt][i] = pk[(slot++) * ps]; xi_ev[tt][i] = pk[(slot++) * ps];
+                    }
+                    alpha[tt] = pk[(slot++) * ps];
+                    tl[tt] = __double_as_longlong(pk[(slot++) * ps]);
+                    cl[tt] = __double_as_longlong(pk[(slot++) * ps]);
+                    tid[tt] = (uint64_t)__double_as_longlong(pk[(slot++) * ps]);
+                    stale[tt] = true; momh_c[tt] = 0.0;   // not kept across this region: recomputed at the next step
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) bTv[tt][i] = 0.0;
+                }
+            }
+            PROF_T(p4);
+            PROF_ADD(2, p3, p4);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                double u[LBMPC_MAX_NU];
                 // no QP this step = the oracle's trivial solve with an empty active set: no candidates next step
                 if (valid[t] && !need[t] && hashint[t]) { a.nhint[cl[t]] = 0; hashint[t] = false; }
-                PROF_T(p4);
-                PROF_ADD(2, p3, p4);
                 // u = K x + c(1:nu); EVModeling (ModelingCar.m:36-37); relative dynamics
                 double Ax[NX], Bu[NX], xn[NX];
 #pragma unroll
                 for (int j = 0; j < LBMPC_MAX_NU; ++j) {
                     u[j] = 0.0;
                     if (j < nu) {
-                        double acc = c0[j];
+                        double acc = c0[t][j];
 #pragma unroll
                         for (int i = 0; i < NX; ++i) acc = fma(C->K[j * NX + i], x[t][i], acc);
                         u[j] = acc;
@@ -794,7 +839,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
                         a.out.traj_u[(tl[t] * K + k) * nu + j] = uj;
                     }
                     if (a.out.traj_alpha) a.out.traj_alpha[tl[t] * (K + 1) + k + 1] = alpha[t];
-                    if (a.out.traj_s0) for (int i = 0; i < NX; ++i) a.out.traj_s0[(tl[t] * K + k) * NX + i] = s0[i];
+                    if (a.out.traj_s0) for (int i = 0; i < NX; ++i) a.out.traj_s0[(tl[t] * K + k) * NX + i] = s0[t][i];
                 }
                 PROF_T(p5);
                 PROF_ADD(3, p4, p5);
