@@ -70,6 +70,9 @@ struct lbmpc_ctx {
     unsigned long long* counters = nullptr;  // 8 work counters of the last mc_run
     int* hint = nullptr;                     // pivot candidates, 17 ints per chunk trial (16 rows + count)
     size_t hint_n = 0;
+    double* st_d = nullptr;                  // trial state handed between step segments: (3 nx + 1) doubles ...
+    int* st_i = nullptr;                     // ... and 5 ints per chunk trial
+    size_t st_n = 0;
     double* park = nullptr;                  // state parked during solves, PARK_SLOTS doubles per grid thread
     size_t park_bytes = 0;
 };
@@ -480,6 +483,11 @@ struct McArgs {
     double acc_bound, distance_error;
     int traj_trials, sampler_max_attempts;
     int tpw;  // trials per wave (and per t): 4 .. 64
+    // step segment of this launch: [kseg0, kseg1); resume != 0: every trial continues from its saved state at step
+    // st_i[kpos] (trials whose kpos is not inside the segment idle); state is saved at the end when kseg1 < steps
+    int kseg0, kseg1, resume;
+    double* st_d;  // [3 nx + 1][chunk trial]: x, v, w_new, alpha
+    int* st_i;     // [5][chunk trial]: status, infeasible, iters, hashint, kpos
     // this launch covers local trials [chunk0, chunk0 + chunk_n); xi holds their pre-drawn step disturbances
     int64_t chunk0, chunk_n;
     const double* xi;       // pre-drawn xi_LV / xi_EV, layout xi_index()
@@ -629,6 +637,8 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
         int status[T], infeasible[T], iters[T];
         bool hashint[T];   // the trial's candidate list in HBM is non-empty
         bool stale[T];     // bTv / momh_c must be recomputed
+        int kpos[T];       // first step this trial runs in this launch (resume) / next step to run (at the end)
+        bool live[T];      // valid and inside its step range
         double bTv[T][NX], momh_c[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -638,8 +648,11 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
             tl[t] = a.chunk0 + cl[t];
             tid[t] = (uint64_t)(a.trial0 + tl[t]);
             status[t] = a.steps > 0 ? a.xi_status[cl[t]] : 0; infeasible[t] = 0; iters[t] = 0; hashint[t] = false; stale[t] = true; momh_c[t] = 0.0;
+            kpos[t] = a.resume ? a.st_i[4 * a.chunk_n + cl[t]] : 0;
+            alpha[t] = 1.0;
 #pragma unroll
-            for (int i = 0; i < NX; ++i) bTv[t][i] = 0.0;
+            for (int i = 0; i < NX; ++i) { bTv[t][i] = 0.0; x[t][i] = 0.0; v[t][i] = 0.0; wst[t][i] = 0.0; }
+            if (a.resume) continue;   // state arrives at step kpos
             // initial set learning: InitialSetComputation.solve (:48-59), card_I0 samples
             double m[2 * NX];
 #pragma unroll
@@ -669,7 +682,31 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
                 if (a.out.traj_alpha) a.out.traj_alpha[tl[t] * (K + 1)] = alpha[t];
             }
         }
-        for (int k = 0; k < K; ++k) {
+        {   // nothing to do for this wave in this segment?
+            bool work = false;
+#pragma unroll
+            for (int t = 0; t < T; ++t) work = work || (valid[t] && (!a.resume || kpos[t] < a.kseg1));
+            if (__builtin_amdgcn_ballot_w64(work) == 0) continue;
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) live[t] = valid[t] && !a.resume;
+        for (int k = a.kseg0; k < a.kseg1; ++k) {
+            if (a.resume) {
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+                    if (valid[t] && k == kpos[t]) {  // this trial's saved state takes over from here
+                        const int64_t cn = a.chunk_n, c = cl[t];
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) {
+                            x[t][i] = a.st_d[(0 * NX + i) * cn + c]; v[t][i] = a.st_d[(1 * NX + i) * cn + c];
+                            wst[t][i] = a.st_d[(2 * NX + i) * cn + c];
+                        }
+                        alpha[t] = a.st_d[3 * NX * cn + c];
+                        status[t] = a.st_i[0 * cn + c]; infeasible[t] = a.st_i[1 * cn + c]; iters[t] = a.st_i[2 * cn + c];
+                        hashint[t] = a.st_i[3 * cn + c] != 0;
+                        stale[t] = true; live[t] = true;
+                    }
+            }
             double q[T][NX], xi_lv[T][NX], xi_ev[T][NX], momh[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
@@ -708,12 +745,14 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
             PROF_T(p1);
             // first pass, stage 1 (per step, cheap): ellipsoid test; the H rows contribute min(1 - h_k) exactly
             bool outside[T];
-            bool heavy = ellipsoid_outside<NX, T>(C, alpha, q, outside);
+            bool heavy = false;
+            (void)ellipsoid_outside<NX, T>(C, alpha, q, outside);
             double s0[T][NX], c0[T][LBMPC_MAX_NU];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 need[t] = momh[t] < -QP_TOL_VIOL;
-                heavy = heavy || need[t];
+                outside[t] = outside[t] && live[t];
+                heavy = live[t] && (outside[t] || need[t]);
 #pragma unroll
                 for (int i = 0; i < NX; ++i) s0[t][i] = 0.0;
 #pragma unroll
@@ -759,12 +798,12 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
                     bool nf[T];
                     filter_scan<NX, T>(C, L, a_c, q_c, nf);
 #pragma unroll
-                    for (int t = 0; t < T; ++t) need[t] = need[t] || nf[t];
+                    for (int t = 0; t < T; ++t) need[t] = need[t] || (nf[t] && outside[t]);
                     ctr[0] += T;
                 }
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
-                    const bool nd = valid[t] && need[t];
+                    const bool nd = live[t] && need[t];
 #ifdef LBMPC_PROFILE
                     prof[4] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(nd));
                     prof[5] += (__builtin_popcountll(__builtin_amdgcn_ballot_w64(nd)) + 3) >> 2;
@@ -800,7 +839,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
             for (int t = 0; t < T; ++t) {
                 double u[LBMPC_MAX_NU];
                 // no QP this step = the oracle's trivial solve with an empty active set: no candidates next step
-                if (valid[t] && !need[t] && hashint[t]) { a.nhint[cl[t]] = 0; hashint[t] = false; }
+                if (live[t] && !need[t] && hashint[t]) { a.nhint[cl[t]] = 0; hashint[t] = false; }
                 // u = K x + c(1:nu); EVModeling (ModelingCar.m:36-37); relative dynamics
                 double Ax[NX], Bu[NX], xn[NX];
 #pragma unroll
@@ -830,7 +869,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
                     x[t][i] = xn[i];
                     if (xn[i] > a.distance_error || xn[i] < -a.distance_error) infeasible[t] = 1;
                 }
-                if (valid[t] && tl[t] < a.traj_trials) {
+                if (live[t] && tl[t] < a.traj_trials) {
                     if (a.out.traj_x) for (int i = 0; i < NX; ++i) a.out.traj_x[(tl[t] * (K + 1) + k + 1) * NX + i] = x[t][i];
                     if (a.out.traj_u) for (int j = 0; j < nu; ++j) {
                         double uj = 0.0;
@@ -847,7 +886,19 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
         }
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            if (!valid[t]) continue;
+            if (!live[t]) continue;
+            if (a.kseg1 < K) {  // hand the trial over to the next segment
+                const int64_t cn = a.chunk_n, c = cl[t];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    a.st_d[(0 * NX + i) * cn + c] = x[t][i]; a.st_d[(1 * NX + i) * cn + c] = v[t][i];
+                    a.st_d[(2 * NX + i) * cn + c] = wst[t][i];
+                }
+                a.st_d[3 * NX * cn + c] = alpha[t];
+                a.st_i[0 * cn + c] = status[t]; a.st_i[1 * cn + c] = infeasible[t]; a.st_i[2 * cn + c] = iters[t];
+                a.st_i[3 * cn + c] = hashint[t] ? 1 : 0; a.st_i[4 * cn + c] = a.kseg1;
+                continue;
+            }
             const int64_t l = tl[t];
             if (a.out.infeasible) a.out.infeasible[l] = infeasible[t];
             if (a.out.status) a.out.status[l] = status[t];
@@ -972,6 +1023,8 @@ extern "C" void lbmpc_destroy(lbmpc_ctx* c) {
     if (c->counters) (void)hipFree(c->counters);
     if (c->park) (void)hipFree(c->park);
     if (c->hint) (void)hipFree(c->hint);
+    if (c->st_d) (void)hipFree(c->st_d);
+    if (c->st_i) (void)hipFree(c->st_i);
     delete c;
 }
 
@@ -1216,6 +1269,18 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
         c->hint_n = (size_t)chunk;
     }
     a.hint = c->hint; a.nhint = c->hint + (size_t)c->hint_n * 16;
+    // step segments: [0, ksplit) by the full kernel, the rest resumed from the saved state (LBMPC_MC_SPLIT, testing)
+    int ksplit = cfg->steps;
+    if (const char* env_s = getenv("LBMPC_MC_SPLIT")) { const int v = atoi(env_s); if (v > 0 && v < cfg->steps) ksplit = v; }
+    if (ksplit < cfg->steps && (size_t)chunk > c->st_n) {
+        if (c->st_d) LB_HIP(hipFree(c->st_d));
+        if (c->st_i) LB_HIP(hipFree(c->st_i));
+        c->st_d = nullptr; c->st_i = nullptr; c->st_n = 0;
+        LB_HIP(hipMalloc((void**)&c->st_d, (size_t)chunk * (3 * c->h.nx + 1) * sizeof(double)));
+        LB_HIP(hipMalloc((void**)&c->st_i, (size_t)chunk * 5 * sizeof(int)));
+        c->st_n = (size_t)chunk;
+    }
+    a.st_d = c->st_d; a.st_i = c->st_i;
     a.xi = c->xi; a.xi_status = c->xi_status; a.counters = c->counters;
     for (int64_t c0 = 0; c0 < cfg->trials; c0 += chunk) {
         const int64_t cn = cfg->trials - c0 < chunk ? cfg->trials - c0 : chunk;
@@ -1256,16 +1321,24 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
         if (int rc = allow_lds(mc_kernel<NXV, TV>, lds)) return rc;                             \
         hipLaunchKernelGGL((mc_kernel<NXV, TV>), grid, blk, lds, st, c->d, sd, a);              \
     } while (0)
-        switch (c->h.nx * 2 + (wide ? 1 : 0)) {
-            case 2: LAUNCH_MC(1, 1); break;
-            case 3: LAUNCH_MC(1, 2); break;
-            case 4: LAUNCH_MC(2, 1); break;
-            case 5: LAUNCH_MC(2, 2); break;
-            case 6: LAUNCH_MC(3, 1); break;
-            case 7: LAUNCH_MC(3, 2); break;
-            case 8: LAUNCH_MC(4, 1); break;
-            default: LAUNCH_MC(4, 2); break;
+#define LAUNCH_MC_ALL()                                                                         \
+    switch (c->h.nx * 2 + (wide ? 1 : 0)) {                                                     \
+        case 2: LAUNCH_MC(1, 1); break;                                                         \
+        case 3: LAUNCH_MC(1, 2); break;                                                         \
+        case 4: LAUNCH_MC(2, 1); break;                                                         \
+        case 5: LAUNCH_MC(2, 2); break;                                                         \
+        case 6: LAUNCH_MC(3, 1); break;                                                         \
+        case 7: LAUNCH_MC(3, 2); break;                                                         \
+        case 8: LAUNCH_MC(4, 1); break;                                                         \
+        default: LAUNCH_MC(4, 2); break;                                                        \
+    }
+        a.kseg0 = 0; a.kseg1 = ksplit; a.resume = 0;
+        LAUNCH_MC_ALL();
+        if (ksplit < cfg->steps) {
+            a.kseg0 = ksplit; a.kseg1 = cfg->steps; a.resume = 1;
+            LAUNCH_MC_ALL();
         }
+#undef LAUNCH_MC_ALL
 #undef LAUNCH_MC
         LB_HIP(hipGetLastError());
     }

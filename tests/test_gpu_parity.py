@@ -427,3 +427,21 @@ def test_mc_trials_per_wave_invariance(core, P, smp):
     finally:
         os.environ.pop("LBMPC_MC_TPW", None)
     ctx.close()
+
+
+@pytest.mark.parametrize("split", ["1", "5", "11"])
+def test_mc_step_segments_match_single_launch(core, P, smp, split):
+    """the horizon can be run in step segments with the trial state handed over through HBM (LBMPC_MC_SPLIT forces a
+    split point); results are bitwise those of the single launch, trajectories included"""
+    import os
+    ctx = core.Context(P)
+    kw = dict(trials=333, steps=12, card_I0=10, seed=17, x0=[-12.0, 5.0], acc_bound=2.0, distance_error=15.0, traj_trials=333)
+    one = ctx.mc_run(smp, **kw)
+    try:
+        os.environ["LBMPC_MC_SPLIT"] = split
+        two = ctx.mc_run(smp, **kw)
+    finally:
+        os.environ.pop("LBMPC_MC_SPLIT", None)
+    for k in one:
+        np.testing.assert_array_equal(one[k], two[k], err_msg=k)
+    ctx.close()
