@@ -921,6 +921,149 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
     }
 #endif
 }
+// ---- steady-state closed loop -----------------------------------------------------------------------
+// After the transient no trial needs a QP (C4: none after step 8 of 1000): a step is the set update, the kept
+// tightening, the first-pass filter (ellipsoid test; packed-fp32 row scan when a lane is outside) and the plant update
+// with z = 0.  This kernel runs exactly those steps, lane per trial, with none of the solver's registers or LDS (only
+// the fp32 S rows are staged): several blocks per CU instead of 2 waves per SIMD, so the per-step latencies overlap.
+// A trial whose filter asks for a QP stops with its state saved BEFORE that step; the resume launch of mc_kernel
+// takes it from there (same arithmetic, so the split is invisible in the results).
+template <int NX>
+__global__ __launch_bounds__(256) void mc_steady_kernel(const CtxDev* __restrict__ C, McArgs a) {
+    extern __shared__ double lds[];
+    float* s32 = reinterpret_cast<float*>(lds);
+    {
+        const int n = C->nSp * C->RL;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) s32[i] = C->S32[i];
+        __syncthreads();
+    }
+    LdsView L;
+    L.Srow = nullptr; L.Hm = nullptr; L.Ginv = nullptr; L.S32 = s32;
+    const int nu = C->nu, K = a.steps;
+    const int64_t cn = a.chunk_n;
+    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = l < cn;
+    const int64_t c = valid ? l : cn - 1;
+    const int64_t tl = a.chunk0 + c;
+    unsigned nfilter = 0, nsteps = 0;
+    double x[NX], v[NX], wst[NX], alpha;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        x[i] = a.st_d[(0 * NX + i) * cn + c]; v[i] = a.st_d[(1 * NX + i) * cn + c]; wst[i] = a.st_d[(2 * NX + i) * cn + c];
+    }
+    alpha = a.st_d[3 * NX * cn + c];
+    int status = a.st_i[0 * cn + c], infeasible = a.st_i[1 * cn + c];
+    bool hashint = a.st_i[3 * cn + c] != 0;
+    bool active = valid && a.st_i[4 * cn + c] == a.kseg0;
+    bool stale = true;
+    double bTv[NX], momh_c = 0.0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) bTv[i] = 0.0;
+    for (int k = a.kseg0; k < a.kseg1; ++k) {
+        if (__builtin_amdgcn_ballot_w64(active) == 0) break;
+        double xi_lv[NX], xi_ev[NX];
+        {
+            const double* xl = a.xi + xi_index<NX>(0, c, k, K, cn);
+            const double* xe = a.xi + xi_index<NX>(1, c, k, K, cn);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { xi_lv[i] = xl[i]; xi_ev[i] = xe[i]; }
+        }
+        // online set update on a copy: committed only if the trial does not stop at this step
+        double an[1] = {alpha}, vn[NX], bh[2 * NX], q[1][NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) vn[i] = v[i];
+        bool changed = false;
+        const int st = uq_update<NX>(C, an[0], vn, wst, bh, &changed);
+        int aomh;
+        if (__builtin_amdgcn_ballot_w64(changed || stale) != 0) {
+            tighten_set<NX>(C, an[0], vn, bTv, momh_c, aomh);
+            stale = false;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) q[0][i] = bTv[i] - x[i];
+        bool outside[1], need = momh_c < -QP_TOL_VIOL;
+        (void)ellipsoid_outside<NX, 1>(C, an, q, outside);
+        outside[0] = outside[0] && active;
+        nsteps += 1;
+        if (__builtin_amdgcn_ballot_w64(outside[0]) != 0) {
+            bool nf[1];
+            filter_scan<NX, 1>(C, L, an, q, nf);
+            need = need || (nf[0] && outside[0]);
+            nfilter += 1;
+        }
+        if (active && need) {  // hand this trial to the solver kernel, state as it was before this step
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                a.st_d[(0 * NX + i) * cn + c] = x[i]; a.st_d[(1 * NX + i) * cn + c] = v[i]; a.st_d[(2 * NX + i) * cn + c] = wst[i];
+            }
+            a.st_d[3 * NX * cn + c] = alpha;
+            a.st_i[0 * cn + c] = status; a.st_i[1 * cn + c] = infeasible;
+            a.st_i[3 * cn + c] = hashint ? 1 : 0; a.st_i[4 * cn + c] = k;
+            active = false;
+        }
+        if (active) {
+            alpha = an[0];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) v[i] = vn[i];
+            status = st > status ? st : status;
+            if (hashint) { a.nhint[c] = 0; hashint = false; }  // no QP this step: no pivot candidates next step
+            // u = K x (c = 0); plant update in relative coordinates, as in mc_kernel
+            double u[LBMPC_MAX_NU], Ax[NX], Bu[NX], xn[NX];
+#pragma unroll
+            for (int j = 0; j < LBMPC_MAX_NU; ++j) {
+                u[j] = 0.0;
+                if (j < nu) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) acc = fma(C->K[j * NX + i], x[i], acc);
+                    u[j] = acc;
+                    if (acc > a.acc_bound || acc < -a.acc_bound) infeasible = 1;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double acc = 0.0, bcc = 0.0;
+#pragma unroll
+                for (int kk = 0; kk < NX; ++kk) acc = fma(C->A[i * NX + kk], x[kk], acc);
+#pragma unroll
+                for (int j = 0; j < LBMPC_MAX_NU; ++j) if (j < nu) bcc = fma(C->B[i * nu + j], u[j], bcc);
+                Ax[i] = acc; Bu[i] = bcc;
+                xn[i] = ((Ax[i] + Bu[i]) + xi_ev[i]) - xi_lv[i];
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                wst[i] = (xn[i] - Ax[i]) - Bu[i];
+                x[i] = xn[i];
+                if (xn[i] > a.distance_error || xn[i] < -a.distance_error) infeasible = 1;
+            }
+            if (tl < a.traj_trials) {
+                if (a.out.traj_x) for (int i = 0; i < NX; ++i) a.out.traj_x[(tl * (K + 1) + k + 1) * NX + i] = x[i];
+                if (a.out.traj_u) for (int j = 0; j < nu; ++j) {
+                    double uj = 0.0;
+#pragma unroll
+                    for (int jj = 0; jj < LBMPC_MAX_NU; ++jj) if (jj == j) uj = u[jj];
+                    a.out.traj_u[(tl * K + k) * nu + j] = uj;
+                }
+                if (a.out.traj_alpha) a.out.traj_alpha[tl * (K + 1) + k + 1] = alpha;
+                if (a.out.traj_s0) for (int i = 0; i < NX; ++i) a.out.traj_s0[(tl * K + k) * NX + i] = 0.0;
+            }
+        }
+    }
+    if (active) {  // reached the end of the segment (= the horizon: this kernel always runs to a.steps)
+        a.st_i[4 * cn + c] = a.kseg1;
+        if (a.out.infeasible) a.out.infeasible[tl] = infeasible;
+        if (a.out.status) a.out.status[tl] = status;
+        if (a.out.qp_iters) a.out.qp_iters[tl] = a.st_i[2 * cn + c];
+        if (a.out.alpha_final) a.out.alpha_final[tl] = alpha;
+        if (a.out.v_final) for (int i = 0; i < NX; ++i) a.out.v_final[tl * NX + i] = v[i];
+        if (a.out.x_final) for (int i = 0; i < NX; ++i) a.out.x_final[tl * NX + i] = x[i];
+    }
+    if (lane_id() == 0 && a.counters) {
+        atomicAdd(a.counters + 0, (unsigned long long)nfilter);
+        atomicAdd(a.counters + 1, (unsigned long long)nsteps);
+    }
+}
+
 #ifdef LBMPC_PROFILE
 extern "C" int lbmpc_prof_read_waves(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(lbmpc_prof_wave), sizeof(unsigned long long) * 3 * 4096) == hipSuccess ? 0 : -1;
@@ -1270,8 +1413,13 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
     }
     a.hint = c->hint; a.nhint = c->hint + (size_t)c->hint_n * 16;
     // step segments: [0, ksplit) by the full kernel, the rest resumed from the saved state (LBMPC_MC_SPLIT, testing)
-    int ksplit = cfg->steps;
-    if (const char* env_s = getenv("LBMPC_MC_SPLIT")) { const int v = atoi(env_s); if (v > 0 && v < cfg->steps) ksplit = v; }
+    // Long horizons: the first steps (transient, QPs) by mc_kernel, the rest by mc_steady_kernel, then a resume launch
+    // of mc_kernel for the trials the steady kernel had to hand back (normally none).
+    int ksplit = cfg->steps >= 64 ? 32 : cfg->steps;
+    if (const char* env_s = getenv("LBMPC_MC_SPLIT")) { const int v = atoi(env_s); ksplit = (v > 0 && v < cfg->steps) ? v : cfg->steps; }
+    const char* env_l = getenv("LBMPC_MC_LEAN");
+    const bool lean = !(env_l && atoi(env_l) == 0);
+    const size_t lds_steady = (((size_t)c->h.nSp * c->h.RL * 4 + 15) / 16) * 16;
     if (ksplit < cfg->steps && (size_t)chunk > c->st_n) {
         if (c->st_d) LB_HIP(hipFree(c->st_d));
         if (c->st_i) LB_HIP(hipFree(c->st_i));
@@ -1336,7 +1484,17 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
         LAUNCH_MC_ALL();
         if (ksplit < cfg->steps) {
             a.kseg0 = ksplit; a.kseg1 = cfg->steps; a.resume = 1;
-            LAUNCH_MC_ALL();
+            if (lean) {
+                dim3 g2((unsigned)((cn + 255) / 256)), b2(256);
+                switch (c->h.nx) {
+                    case 1: if (int rc = allow_lds(mc_steady_kernel<1>, lds_steady)) return rc; hipLaunchKernelGGL((mc_steady_kernel<1>), g2, b2, lds_steady, st, c->d, a); break;
+                    case 2: if (int rc = allow_lds(mc_steady_kernel<2>, lds_steady)) return rc; hipLaunchKernelGGL((mc_steady_kernel<2>), g2, b2, lds_steady, st, c->d, a); break;
+                    case 3: if (int rc = allow_lds(mc_steady_kernel<3>, lds_steady)) return rc; hipLaunchKernelGGL((mc_steady_kernel<3>), g2, b2, lds_steady, st, c->d, a); break;
+                    default: if (int rc = allow_lds(mc_steady_kernel<4>, lds_steady)) return rc; hipLaunchKernelGGL((mc_steady_kernel<4>), g2, b2, lds_steady, st, c->d, a); break;
+                }
+                LB_HIP(hipGetLastError());
+            }
+            LAUNCH_MC_ALL();   // trials whose saved step is before the horizon's end (all of them without the lean kernel)
         }
 #undef LAUNCH_MC_ALL
 #undef LAUNCH_MC

@@ -429,19 +429,37 @@ def test_mc_trials_per_wave_invariance(core, P, smp):
     ctx.close()
 
 
+@pytest.mark.parametrize("lean", ["0", "1"])
 @pytest.mark.parametrize("split", ["1", "5", "11"])
-def test_mc_step_segments_match_single_launch(core, P, smp, split):
-    """the horizon can be run in step segments with the trial state handed over through HBM (LBMPC_MC_SPLIT forces a
-    split point); results are bitwise those of the single launch, trajectories included"""
+def test_mc_step_segments_match_single_launch(core, P, smp, split, lean):
+    """long horizons run in step segments with the trial state handed over through HBM: mc_kernel for the transient,
+    mc_steady_kernel for the rest (lean=1; trials that still need a QP are handed back to a resume launch of
+    mc_kernel, which here -- split inside the transient -- is most of them) or mc_kernel again (lean=0).
+    LBMPC_MC_SPLIT forces the split point; results are bitwise those of the single launch, trajectories included"""
     import os
     ctx = core.Context(P)
     kw = dict(trials=333, steps=12, card_I0=10, seed=17, x0=[-12.0, 5.0], acc_bound=2.0, distance_error=15.0, traj_trials=333)
-    one = ctx.mc_run(smp, **kw)
     try:
+        os.environ["LBMPC_MC_SPLIT"] = "0"      # single launch
+        one = ctx.mc_run(smp, **kw)
         os.environ["LBMPC_MC_SPLIT"] = split
+        os.environ["LBMPC_MC_LEAN"] = lean
         two = ctx.mc_run(smp, **kw)
     finally:
         os.environ.pop("LBMPC_MC_SPLIT", None)
+        os.environ.pop("LBMPC_MC_LEAN", None)
     for k in one:
         np.testing.assert_array_equal(one[k], two[k], err_msg=k)
     ctx.close()
+
+
+def test_mc_long_horizon_default_split_vs_oracle(core):
+    """the default policy (steps >= 64: 32 transient steps, then the steady-state kernel) against the oracle on 4x4"""
+    from lbmpc import params
+    Pg = params.load("4x4")
+    smpg = params.sampler(Pg, oriented=True)
+    ctx, octx = core.Context(Pg), oracle_core.Context(Pg)
+    kw = dict(trials=192, steps=80, card_I0=10, seed=4, x0=[-12.0, 5.0, 0.0, 0.0], acc_bound=float(Pg["acc_bound"][0]),
+              distance_error=float(Pg["distance_error"][0]), traj_trials=192)
+    compare_mc(ctx.mc_run(smpg, **kw), octx.mc_run(smpg, **kw))
+    ctx.close(); octx.close()
