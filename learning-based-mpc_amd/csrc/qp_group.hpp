@@ -246,7 +246,6 @@ template <int NX>
 __device__ __forceinline__ void candidate_pivot(const CtxDev* __restrict__ C, const LdsView& L, const double* gws, double alpha,
                                                 const double* q, double my_z, int my_act, int nq, bool need, int cand0,
                                                 int cand1, double& best, int& bj) {
-    const int i = lane_id() & 15;
     const int nS = C->nS, nc = C->nc, nz = C->nz, nzp = C->nzp;
     double e[NX];
     static_for<0, NX>([&](auto K) { constexpr int k = K; e[k] = q[k] + rowb<k>(my_z); });

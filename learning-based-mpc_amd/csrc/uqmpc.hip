@@ -190,10 +190,6 @@ __device__ __forceinline__ double hk_value(const CtxDev* __restrict__ C, double 
     return alpha * C->hs[r] + (1.0 - alpha) * g;
 }
 
-// First pass at z = 0 for the T trials of this lane: min_j slack_j with slack_j = alpha S_b[j] + S_A[j,:].q over
-// the S rows (each row one LDS broadcast, shared by the 64*T trials of the wave); the H rows contribute
-// exactly 1-h_k[r] at z = 0.  Only "is any row violated" is needed here: the pivot itself is found by
-// the cooperative solver, which recomputes the same values.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // One chunk of 8 rows (4 interleaved row pairs), packed fp32: per pair 1 pk_mul + NX pk_fma + 1 min3.
