@@ -8,6 +8,7 @@
 // fit the scalar cache for every W of the reference: nV <= 16, s <= ~30) and feed v_fma_f64 as SGPR
 // operands, so the sweep is bound by the fp64 vector rate, not by LDS or HBM (DESIGN.md "Kernel 1").
 #include <cmath>
+#include <mutex>
 #include <vector>
 
 #include "common.hpp"
@@ -137,13 +138,24 @@ extern "C" int lbmpc_support_batch_dev(const double* A, int nx, const double* Vw
     hipStream_t st = (hipStream_t)stream;
     std::vector<double> G;
     stack_G(A, nx, Vw, nV, s, transpose_flag, G);
-    void* dG = nullptr;
-    LB_HIP(hipMallocAsync(&dG, G.size() * 8, st));
-    LB_HIP(hipMemcpyAsync(dG, G.data(), G.size() * 8, hipMemcpyHostToDevice, st));
-    LB_HIP(hipStreamSynchronize(st));  // G is a stack temporary
-    int rc = launch_support((const double*)dG, nx, s, nV, 1.0 / (1.0 - alpha), D_dev, nd, h_out_dev, st);
-    (void)hipFreeAsync(dG, st);
-    return rc;
+    // The stacked G of the last call stays on its device: repeated sweeps with the same (A, V_W, s) -- the usual
+    // pattern, e.g. the s/alpha loop or a direction batch per solver call -- skip the allocation, the copy and the
+    // synchronisation (which cost twice the kernel's time at 1M directions).  One entry per process, guarded.
+    static std::mutex mu;
+    static std::vector<double> cachedG;
+    static void* cachedDev = nullptr;
+    static int cachedDevice = -1;
+    std::lock_guard<std::mutex> lock(mu);
+    int device = 0;
+    LB_HIP(hipGetDevice(&device));
+    if (!(cachedDev && cachedDevice == device && cachedG == G)) {
+        LB_HIP(hipDeviceSynchronize());  // earlier launches may still read the previous entry
+        if (cachedDev) { (void)hipFree(cachedDev); cachedDev = nullptr; cachedG.clear(); }
+        LB_HIP(hipMalloc(&cachedDev, G.size() * 8));
+        LB_HIP(hipMemcpy(cachedDev, G.data(), G.size() * 8, hipMemcpyHostToDevice));
+        cachedG = G; cachedDevice = device;
+    }
+    return launch_support((const double*)cachedDev, nx, s, nV, 1.0 / (1.0 - alpha), D_dev, nd, h_out_dev, st);
 }
 
 extern "C" int lbmpc_support_batch(const double* A, int nx, const double* Vw, int nV, int s, double alpha,
