@@ -463,3 +463,32 @@ def test_mc_long_horizon_default_split_vs_oracle(core):
               distance_error=float(Pg["distance_error"][0]), traj_trials=192)
     compare_mc(ctx.mc_run(smpg, **kw), octx.mc_run(smpg, **kw))
     ctx.close(); octx.close()
+
+
+def test_mc_c4_full_size_slices_vs_oracle(core):
+    """C4 at BASELINE.json's full size on one GPU (131072 trials x 1000 steps, card(I0) = 10, seed 4, the bench's
+    proposal boxes): the first and the last 96 trials of the full launch against the oracle run on those trial ids
+    (flags, iteration counts bit-exact; final set and state within the tolerances above), and the two half-size shards
+    the 2-GPU driver would issue reproduce the full launch bitwise"""
+    from lbmpc import params
+    Pg = params.load("4x4")
+    smpg = params.sampler(Pg, oriented=True)
+    ctx, octx = core.Context(Pg), oracle_core.Context(Pg)
+    n, w = 131072, 96
+    kw = dict(steps=1000, card_I0=10, seed=4, x0=[-12.0, 5.0, 0.0, 0.0], acc_bound=float(Pg["acc_bound"][0]),
+              distance_error=float(Pg["distance_error"][0]))
+    full = ctx.mc_run(smpg, trials=n, **kw)
+    for t0 in (0, n - w):
+        o = octx.mc_run(smpg, trials=w, trial0=t0, **kw)
+        sl = slice(t0, t0 + w)
+        for k in ("infeasible", "status", "qp_iters"):
+            np.testing.assert_array_equal(full[k][sl], o[k], err_msg=f"{k} trial0={t0}")
+        for k in ("alpha0", "alpha_final", "v_final"):
+            np.testing.assert_allclose(full[k][sl], o[k], rtol=SET_RTOL, atol=1e-15, err_msg=f"{k} trial0={t0}")
+        np.testing.assert_allclose(full["x_final"][sl], o["x_final"], rtol=QP_TOL, atol=QP_TOL, err_msg=f"x_final trial0={t0}")
+    a = ctx.mc_run(smpg, trials=n // 2, trial0=0, **kw)
+    b = ctx.mc_run(smpg, trials=n // 2, trial0=n // 2, **kw)
+    for k in ("infeasible", "status", "qp_iters", "alpha0", "alpha_final", "v_final", "x_final"):
+        np.testing.assert_array_equal(full[k], np.concatenate([a[k], b[k]]), err_msg=k)
+    assert full["infeasible"].sum() == 0 and full["qp_iters"].min() > 0
+    ctx.close(); octx.close()
