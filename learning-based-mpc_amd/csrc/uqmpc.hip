@@ -5,17 +5,19 @@
 // loops of Cases_general/Case_{3,4,5}.
 //
 // Execution model (DESIGN.md "Kernel 3"):
-//   * a wave owns 64*T independent problems / trials, one per lane (T per lane);
-//   * phase A (lane-per-trial): plant sampling, online set update (closed-form homothety LP), h_k
-//     in closed form, and the first pass over the QP rows at the unconstrained minimiser z = 0
-//     (only the nS rows of S_hat can differ from their right-hand side there); the row
-//     coefficients are LDS broadcasts shared by the 64*T trials of the wave;
-//   * phase B (wave-cooperative, only for trials whose first pass found a violated row): the
-//     Goldfarb-Idnani dual active-set method; the 64 lanes stride the m constraint rows (one LDS
-//     row per lane, odd row pitch => conflict-free), arg-min by wave shuffles, the <=16x16
-//     Cholesky factor / KKT vectors live in a per-wave LDS workspace and registers;
-//   * phase C (lane-per-trial): u = K x + c_0, plant update, violation flags.
-// Constants ([S_b | S_A] rows, F_bar Psi^i rows, (2P)^-1) are staged once per block into LDS.
+//   * mc_sample_kernel (pre-pass): the step disturbances xi_LV + B u_LV and xi_EV of a trial chunk, four adjacent
+//     trials per thread, stored step-major so that both this kernel's stores and the step loop's loads are whole lines;
+//   * mc_kernel / uqmpc_step_kernel, lane per trial (T trials per lane): online set update (closed-form homothety LP),
+//     h_k in closed form, then the first pass at the unconstrained minimiser z = 0 as a conservative filter -- inscribed
+//     ellipsoid test, then a packed-fp32 scan of the S rows with a rounding margin -- so that only trials that may
+//     have a violated row reach the solver;
+//   * solver (qp_group.hpp): Goldfarb-Idnani dual active set, one QP per 16-lane DPP row, four QPs per wave; the row
+//     scan reads each LDS row once for all four QPs; the factor and the KKT vectors live in registers, one column per
+//     lane; closed-loop state is parked in HBM while the solver needs the registers;
+//   * u = K x + c_0, plant update, violation flags, lane per trial again;
+//   * long horizons run in step segments: mc_kernel for the transient, mc_steady_kernel (no solver, several blocks per
+//     CU) for the steps where no trial needs a QP, and a resume launch of mc_kernel for the trials that did after all.
+// Constants ([S_b | S_A] rows in fp64 and fp32, F_bar Psi^i rows, (2P)^-1) are staged once per block into LDS.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -213,14 +215,8 @@ __device__ __forceinline__ void first_pass_eval(const float4* cur, const float* 
     }
 }
 
-// First pass at z = 0 for the T trials of this lane: is any S row violated?  slack_j = alpha S_b[j] + S_A[j,:].q ; the
-// H rows contribute exactly 1-h_k[r] (min_omh, exact).  This is only a FILTER in front of the exact solver (whose
-// own fp64 scan decides, and returns z = 0 after zero iterations when nothing is violated), so it runs in packed
-// fp32 -- every row pair is one LDS broadcast shared by the 64*T trials of the wave -- and flags a trial whenever
-// the fp32 minimum is below -tol + margin, margin = 2^-20 (alpha max|S_b| + sum_k max|S_A[:,k]| |q_k|) >= twice the
-// worst-case rounding error (gamma_7, u = 2^-24) of any row.  A violated row is therefore never missed; a false
-// alarm costs one scan.  NaN / overflow compare as "flagged".
-// Ellipsoid early-out of the first pass: outside[t] = the trial is NOT proven free of violated S rows.
+// First stage of the first-pass filter, the inscribed ellipsoid of S (CtxDev::ME): outside[t] = the trial is NOT
+// proven free of violated S rows.
 template <int NX, int T>
 __device__ __forceinline__ bool ellipsoid_outside(const CtxDev* __restrict__ C, const double* alpha, const double (*q)[NX],
                                                   bool* outside) {
@@ -244,7 +240,13 @@ __device__ __forceinline__ bool ellipsoid_outside(const CtxDev* __restrict__ C, 
     return any;
 }
 
-// Packed-fp32 scan of the S rows (second stage of the first-pass filter): need[t] = some row may be violated.
+// Second stage, the packed-fp32 scan of the S rows at z = 0 for the T trials of this lane: may any S row be violated?  slack_j = alpha S_b[j] + S_A[j,:].q ; the
+// H rows contribute exactly 1-h_k[r] (min_omh, exact).  This is only a FILTER in front of the exact solver (whose
+// own fp64 scan decides, and returns z = 0 after zero iterations when nothing is violated), so it runs in packed
+// fp32 -- every row pair is one LDS broadcast shared by the 64*T trials of the wave -- and flags a trial whenever
+// the fp32 minimum is below -tol + margin, margin = 2^-20 (alpha max|S_b| + sum_k max|S_A[:,k]| |q_k|) >= twice the
+// worst-case rounding error (gamma_7, u = 2^-24) of any row.  A violated row is therefore never missed; a false
+// alarm costs one scan.  NaN / overflow compare as "flagged".
 template <int NX, int T>
 __device__ __forceinline__ void filter_scan(const CtxDev* __restrict__ C, const LdsView& L, const double* alpha,
                                             const double (*q)[NX], bool* need) {
@@ -422,14 +424,12 @@ __global__ __launch_bounds__(256) void uqmpc_step_kernel(const CtxDev* __restric
         for (int k = 0; k < NX; ++k) s0[k] = 0.0;
 #pragma unroll
         for (int j = 0; j < LBMPC_MAX_NU; ++j) c0[j] = 0.0;
-        int act_sorted[NZMAX];
         double* cdst = (valid && io.c) ? io.c + b * ncv : nullptr;
         if (cdst) for (int k = 0; k < ncv; ++k) cdst[k] = 0.0;
         if (valid && io.active_set) for (int a = 0; a < NZMAX; ++a) io.active_set[b * NZMAX + a] = -1;
         unsigned ctr[5] = {0, 0, 0, 0, 0};
         solve_flagged<NX>(C, L, ws, valid && need[0], alpha[0], v, q[0], s0, c0, status, iters,
                           &nact, (valid && io.active_set) ? io.active_set + b * NZMAX : nullptr, cdst, ctr, nullptr, nullptr, 0);
-        (void)act_sorted;
         if (!valid) continue;
         if (io.s0) for (int k = 0; k < NX; ++k) io.s0[b * NX + k] = s0[k];
         if (io.u)
@@ -568,9 +568,6 @@ __device__ __forceinline__ void mc_sample_body(const SamplerDev& smp, int64_t ch
                 att = 0;
                 if (j == 3) {
                     double* dst = xi + xi_index<NX>(kind, cl0, k, K, chunk_n);
-#ifdef LBMPC_ABLATE_XI_STORE
-                    if (k == kend - 1)
-#endif
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
@@ -709,11 +706,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
                 const double* xl = a.xi + xi_index<NX>(0, cl[t], k, K, a.chunk_n);
                 const double* xe = a.xi + xi_index<NX>(1, cl[t], k, K, a.chunk_n);
 #pragma unroll
-#ifdef LBMPC_ABLATE_XI_LOAD
-                for (int i = 0; i < NX; ++i) { xi_lv[t][i] = 1e-3 * (double)((tid[t] + k + i) & 7); xi_ev[t][i] = 1e-3 * (double)((tid[t] + 3 * k + i) & 7); (void)xl; (void)xe; }
-#else
                 for (int i = 0; i < NX; ++i) { xi_lv[t][i] = xl[i]; xi_ev[t][i] = xe[i]; }
-#endif
             }
             int aomh[T];
             bool need[T];
@@ -748,7 +741,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
             for (int t = 0; t < T; ++t) {
                 need[t] = momh[t] < -QP_TOL_VIOL;
                 outside[t] = outside[t] && live[t];
-                heavy = live[t] && (outside[t] || need[t]);
+                heavy = heavy || (live[t] && (outside[t] || need[t]));
 #pragma unroll
                 for (int i = 0; i < NX; ++i) s0[t][i] = 0.0;
 #pragma unroll
@@ -1408,9 +1401,9 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
         c->hint_n = (size_t)chunk;
     }
     a.hint = c->hint; a.nhint = c->hint + (size_t)c->hint_n * 16;
-    // step segments: [0, ksplit) by the full kernel, the rest resumed from the saved state (LBMPC_MC_SPLIT, testing)
-    // Long horizons: the first steps (transient, QPs) by mc_kernel, the rest by mc_steady_kernel, then a resume launch
-    // of mc_kernel for the trials the steady kernel had to hand back (normally none).
+    // Long horizons run in step segments: [0, ksplit) (transient, QPs) by mc_kernel, the rest by mc_steady_kernel from
+    // the saved state, then a resume launch of mc_kernel for the trials the steady kernel had to hand back (normally
+    // none).  LBMPC_MC_SPLIT moves the split point and LBMPC_MC_LEAN=0 leaves the steady kernel out (testing).
     int ksplit = cfg->steps >= 64 ? 32 : cfg->steps;
     if (const char* env_s = getenv("LBMPC_MC_SPLIT")) { const int v = atoi(env_s); ksplit = (v > 0 && v < cfg->steps) ? v : cfg->steps; }
     const char* env_l = getenv("LBMPC_MC_LEAN");

@@ -296,10 +296,11 @@ def test_mc_sharding_invariance(core, P, smp):
 
 
 def test_mc_wide_path_matches_narrow(core, P, smp):
-    """2 trials per lane (chosen automatically from 262144 trials; forced here) == 1 trial per lane, bitwise"""
+    """2 trials per lane (chosen automatically from 524288 trials; forced here) == 1 trial per lane, bitwise.  1003
+    trials: the last wave holds three trials in its first slot and none in its second"""
     import os
     ctx = core.Context(P)
-    kw = dict(trials=1000, steps=8, card_I0=10, seed=4, x0=[-12.0, 5.0], acc_bound=2.0, distance_error=15.0)
+    kw = dict(trials=1003, steps=8, card_I0=10, seed=4, x0=[-12.0, 5.0], acc_bound=2.0, distance_error=15.0)
     try:
         os.environ["LBMPC_MC_T"] = "2"
         wide = ctx.mc_run(smp, **kw)
