@@ -493,3 +493,22 @@ def test_mc_c4_full_size_slices_vs_oracle(core):
         np.testing.assert_array_equal(full[k], np.concatenate([a[k], b[k]]), err_msg=k)
     assert full["infeasible"].sum() == 0 and full["qp_iters"].min() > 0
     ctx.close(); octx.close()
+
+
+def test_mc_two_trials_per_lane_default_vs_oracle(core, P, smp):
+    """from 524288 trials a lane carries two trials (chosen by the library, nothing forced here): the first and the
+    last 64 trials of a ragged batch against the oracle on those trial ids"""
+    ctx, octx = core.Context(P), oracle_core.Context(P)
+    n, w = 524288 + 37, 64
+    kw = dict(steps=12, card_I0=10, seed=31, x0=[-12.0, 5.0], acc_bound=2.0, distance_error=15.0)
+    full = ctx.mc_run(smp, trials=n, **kw)
+    for t0 in (0, n - w):
+        o = octx.mc_run(smp, trials=w, trial0=t0, **kw)
+        sl = slice(t0, t0 + w)
+        for k in ("infeasible", "status", "qp_iters"):
+            np.testing.assert_array_equal(full[k][sl], o[k], err_msg=f"{k} trial0={t0}")
+        for k in ("alpha0", "alpha_final", "v_final"):
+            np.testing.assert_allclose(full[k][sl], o[k], rtol=SET_RTOL, atol=1e-15, err_msg=f"{k} trial0={t0}")
+        np.testing.assert_allclose(full["x_final"][sl], o["x_final"], rtol=QP_TOL, atol=QP_TOL, err_msg=f"x_final trial0={t0}")
+    assert full["qp_iters"].min() > 0
+    ctx.close(); octx.close()
