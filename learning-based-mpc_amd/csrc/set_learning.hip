@@ -178,8 +178,8 @@ static void plan_chunks(int64_t N, int64_t batch, int spl, int* chunks, int64_t*
 
 using namespace lbmpc;
 
-// Scratch for the partial maxima when an information set is split over several waves.  Grown on
-// demand per device, released by lbmpc_shutdown... kept simple: allocate/free per call when needed.
+// An information set split over several waves (chunks > 1) leaves partial maxima in a stream-ordered scratch buffer
+// (hipMallocAsync / hipFreeAsync on the caller's stream: no synchronisation), folded by finish_max_kernel.
 extern "C" int lbmpc_halfspace_max_dev(const double* WA, int nW, int nx, const double* samples_dev, int64_t N,
                                        int64_t batch, int64_t batch_stride, double* m_out_dev, void* stream) {
     if (int rc = check_device()) return rc;
