@@ -512,3 +512,26 @@ def test_mc_two_trials_per_lane_default_vs_oracle(core, P, smp):
         np.testing.assert_allclose(full["x_final"][sl], o["x_final"], rtol=QP_TOL, atol=QP_TOL, err_msg=f"x_final trial0={t0}")
     assert full["qp_iters"].min() > 0
     ctx.close(); octx.close()
+
+
+def test_kernel_3_usage_errors(core, P, smp):
+    """usage errors of the controller entry points come back as negative codes with a message (no exception crosses
+    the ABI, nothing is launched); the reference has no checks here at all"""
+    from lbmpc import params
+    ctx = core.Context(P)
+    kw = dict(trials=8, steps=3, card_I0=10, seed=1, x0=[-12.0, 5.0], acc_bound=2.0, distance_error=15.0)
+    with pytest.raises(core.LbmpcError, match="sampler dims"):
+        P3 = params.load("3x3")
+        ctx.mc_run(params.sampler(P3), **kw)                     # 3x3 disturbance sets on a 2x2 controller
+    with pytest.raises(core.LbmpcError, match="bad configuration"):
+        ctx.mc_run(smp, **dict(kw, card_I0=0))                   # empty initial information set
+    with pytest.raises(core.LbmpcError, match="bad configuration"):
+        ctx.mc_run(smp, **dict(kw, sampler_max_attempts=0))
+    out = ctx.mc_run(smp, **dict(kw, trials=0))                  # nothing to do is not an error
+    assert out["status"].shape == (0,)
+    big = dict(P)
+    big["S_A"] = np.tile(P["S_A"], (80, 1)); big["S_b"] = np.tile(np.ravel(P["S_b"]), 80)   # 6400 rows: beyond the LDS
+    with pytest.raises(core.LbmpcError):
+        c2 = core.Context(big)
+        c2.mc_run(smp, **kw)
+    ctx.close()
