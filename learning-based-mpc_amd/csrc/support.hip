@@ -8,6 +8,7 @@
 // fit the scalar cache for every W of the reference: nV <= 16, s <= ~30) and feed v_fma_f64 as SGPR
 // operands, so the sweep is bound by the fp64 vector rate, not by LDS or HBM (DESIGN.md "Kernel 1").
 #include <cmath>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -96,7 +97,9 @@ static int launch_support(const double* Gdev, int nx, int s, int nV, double scal
                           double* out, hipStream_t st) {
     if (nd == 0) return 0;
     const bool vec = ((uintptr_t)D % 16) == 0;
-    const bool wide = nd >= (int64_t)256 * 8 * 256 * 4;  // enough work for 4 directions per lane
+    // directions per lane: more of them amortise the scalar loads of the G rows once the batch still fills the chip
+    int dpl = nd >= (int64_t)256 * 8 * 256 * 4 ? 4 : (nd >= (int64_t)768 * 1024 ? 2 : 1);
+    if (const char* e = getenv("LBMPC_SUPPORT_DPL")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) dpl = v; }
 #define LS(NXV, DPLV)                                                                                              \
     do {                                                                                                           \
         const int64_t per_block = 256 * (int64_t)DPLV;                                                             \
@@ -104,11 +107,11 @@ static int launch_support(const double* Gdev, int nx, int s, int nV, double scal
         if (vec) hipLaunchKernelGGL((support_kernel<NXV, DPLV, true>), grid, dim3(256), 0, st, Gdev, s, nV, scale, D, nd, out); \
         else hipLaunchKernelGGL((support_kernel<NXV, DPLV, false>), grid, dim3(256), 0, st, Gdev, s, nV, scale, D, nd, out);    \
     } while (0)
-    switch (nx) {
-        case 1: if (wide) LS(1, 4); else LS(1, 1); break;
-        case 2: if (wide) LS(2, 4); else LS(2, 1); break;
-        case 3: if (wide) LS(3, 4); else LS(3, 1); break;
-        default: if (wide) LS(4, 4); else LS(4, 1); break;
+    switch (nx * 8 + dpl) {
+        case 9: LS(1, 1); break;   case 10: LS(1, 2); break;  case 12: LS(1, 4); break;
+        case 17: LS(2, 1); break;  case 18: LS(2, 2); break;  case 20: LS(2, 4); break;
+        case 25: LS(3, 1); break;  case 26: LS(3, 2); break;  case 28: LS(3, 4); break;
+        case 33: LS(4, 1); break;  case 34: LS(4, 2); break;  default: LS(4, 4); break;
     }
 #undef LS
     LB_HIP(hipGetLastError());

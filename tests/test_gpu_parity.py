@@ -128,7 +128,7 @@ def test_support_hs_golden(core, P):
 
 @pytest.mark.parametrize("nx,nV,s,nd,tr", [(2, 4, 7, 1000, True), (2, 4, 11, 77, False), (3, 8, 9, 5000, True),
                                            (4, 16, 10, 100000, True), (4, 16, 30, 4097, True), (1, 2, 5, 300, True),
-                                           (2, 119, 1, 64, True), (4, 16, 8, 3000000, True)])
+                                           (2, 119, 1, 64, True), (4, 16, 8, 3000000, True), (4, 16, 4, 1000001, True)])
 def test_support_batch_vs_oracle(core, nx, nV, s, nd, tr):
     rng = np.random.default_rng(nx + nV + s)
     A = 0.6 * rng.normal(size=(nx, nx)) / np.sqrt(nx)
