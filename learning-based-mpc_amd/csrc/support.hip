@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256) void support_kernel(const double* __restrict__
         double best[DPL];
 #pragma unroll
         for (int u = 0; u < DPL; ++u) best[u] = -LB_INF;
+#pragma unroll 4  // four G rows per scalar-load wait
         for (int v = 0; v < nV; ++v, g += NX) {
             double a[NX];
 #pragma unroll
@@ -97,8 +98,7 @@ static int launch_support(const double* Gdev, int nx, int s, int nV, double scal
                           double* out, hipStream_t st) {
     if (nd == 0) return 0;
     const bool vec = ((uintptr_t)D % 16) == 0;
-    // directions per lane: more of them amortise the scalar loads of the G rows once the batch still fills the chip
-    int dpl = nd >= (int64_t)256 * 8 * 256 * 4 ? 4 : (nd >= (int64_t)768 * 1024 ? 2 : 1);
+    int dpl = nd >= (int64_t)256 * 8 * 256 * 4 ? 4 : 1;  // enough work for 4 directions per lane
     if (const char* e = getenv("LBMPC_SUPPORT_DPL")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) dpl = v; }
 #define LS(NXV, DPLV)                                                                                              \
     do {                                                                                                           \
