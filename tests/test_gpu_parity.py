@@ -535,3 +535,35 @@ def test_kernel_3_usage_errors(core, P, smp):
         c2 = core.Context(big)
         c2.mc_run(smp, **kw)
     ctx.close()
+
+
+def test_device_pointers_without_16_byte_alignment(core, P):
+    """device-pointer entry points with buffers that start 8 bytes off a 16-byte boundary (a slice of a tensor):
+    the kernels fall back from double2 loads to scalar ones, results are those of the aligned call, bitwise"""
+    import torch
+    from lbmpc import dev
+    rng = np.random.default_rng(12)
+    dvc = torch.device("cuda:0")
+    # support sweep, nx = 4
+    A = 0.6 * rng.normal(size=(4, 4)) / 2
+    Vw = rng.uniform(-1, 1, size=(16, 4))
+    D = rng.normal(size=(5001, 4))
+    buf = torch.zeros(5001 * 4 + 1, dtype=torch.float64, device=dvc)
+    buf[1:] = torch.from_numpy(D.ravel()).to(dvc)
+    off = buf[1:].view(5001, 4)
+    assert off.data_ptr() % 16 == 8
+    h_off = dev.support_batch(A, Vw, 6, 0.05, off)
+    h_al = dev.support_batch(A, Vw, 6, 0.05, torch.from_numpy(D).to(dvc))
+    assert torch.equal(h_off, h_al)
+    np.testing.assert_allclose(h_al.cpu().numpy(), oracle_core.support_batch(A, Vw, 6, 0.05, D.T), rtol=SET_RTOL, atol=0)
+    # halfspace max, nx = 2
+    S = rng.uniform(-0.2, 0.2, size=(3, 4097, 2))
+    buf2 = torch.zeros(S.size + 1, dtype=torch.float64, device=dvc)
+    buf2[1:] = torch.from_numpy(S.ravel()).to(dvc)
+    off2 = buf2[1:].view(3, 4097, 2)
+    assert off2.data_ptr() % 16 == 8
+    m_off = dev.halfspace_max(P["W_A"], off2)
+    m_al = dev.halfspace_max(P["W_A"], torch.from_numpy(S).to(dvc))
+    assert torch.equal(m_off, m_al)
+    np.testing.assert_array_equal(m_al.cpu().numpy()[1], oracle_core.halfspace_max(P["W_A"], S[1].T))
+    torch.cuda.synchronize()
