@@ -567,3 +567,26 @@ def test_device_pointers_without_16_byte_alignment(core, P):
     assert torch.equal(m_off, m_al)
     np.testing.assert_array_equal(m_al.cpu().numpy()[1], oracle_core.halfspace_max(P["W_A"], S[1].T))
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("lean", ["0", "1"])
+def test_mc_step_segments_with_two_trials_per_lane(core, P, smp, lean):
+    """the combination large long-horizon batches run with: two trials per lane AND step segments (forced here on a
+    ragged batch), against the plain single launch with one trial per lane"""
+    import os
+    ctx = core.Context(P)
+    kw = dict(trials=1003, steps=12, card_I0=10, seed=19, x0=[-12.0, 5.0], acc_bound=2.0, distance_error=15.0, traj_trials=1003)
+    try:
+        os.environ["LBMPC_MC_SPLIT"] = "0"
+        os.environ["LBMPC_MC_T"] = "1"
+        one = ctx.mc_run(smp, **kw)
+        os.environ["LBMPC_MC_SPLIT"] = "4"
+        os.environ["LBMPC_MC_T"] = "2"
+        os.environ["LBMPC_MC_LEAN"] = lean
+        two = ctx.mc_run(smp, **kw)
+    finally:
+        for k in ("LBMPC_MC_SPLIT", "LBMPC_MC_T", "LBMPC_MC_LEAN"):
+            os.environ.pop(k, None)
+    for k in one:
+        np.testing.assert_array_equal(one[k], two[k], err_msg=k)
+    ctx.close()
