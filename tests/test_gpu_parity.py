@@ -342,10 +342,14 @@ def test_mc_trial_chunks_match_single_launch(core, P, smp):
     try:
         os.environ["LBMPC_MC_XI_GIB"] = "0.0001"   # ~105 kB -> 512-trial chunks
         many = ctx.mc_run(smp, **kw)
+        os.environ["LBMPC_MC_SPLIT"] = "4"         # chunks x step segments: every chunk reuses the hand-over buffers
+        both = ctx.mc_run(smp, **kw)
     finally:
         os.environ.pop("LBMPC_MC_XI_GIB", None)
+        os.environ.pop("LBMPC_MC_SPLIT", None)
     for k in one:
         np.testing.assert_array_equal(one[k], many[k], err_msg=k)
+        np.testing.assert_array_equal(one[k], both[k], err_msg=k + " (chunks x segments)")
     ctx.close()
 
 
