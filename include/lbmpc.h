@@ -12,8 +12,12 @@
  *   - all reals are IEEE fp64; all matrices are COLUMN-MAJOR (MATLAB layout), leading dim = rows.
  *   - "host" entry points take host pointers and copy in/out; "_dev" entry points take device
  *     pointers for the bulk operands (samples, directions, outputs) and a hipStream_t (as void*),
- *     enqueue asynchronously and do not synchronise.  Small constant operands (A, W_A, ...) are
- *     always host pointers.
+ *     enqueue asynchronously and do not synchronise the device.  Small constant operands (A, W_A,
+ *     ...) are always host pointers.  Two of them may ALLOCATE device memory (hipMalloc, which is not
+ *     legal under stream capture): lbmpc_support_batch_dev the first time it sees a parameter set
+ *     (A, V_W, s, transpose) on a device (kept in a small per-process cache afterwards), and
+ *     lbmpc_mc_run_dev when a call needs more scratch than any earlier call on the same context
+ *     (grow-only).  lbmpc_halfspace_max_noalloc is the entry point that never allocates.
  *   - return value: 0 ok; <0 usage error (LBMPC_ERR_*); >0 numerical status (LBMPC_ST_*).
  *     No exceptions cross the ABI.  The reference has no status at all (IPOPT fails silently,
  *     Functions_general/UQRobustMPC.m:156-158).
@@ -28,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LBMPC_VERSION 100 /* 0.1.0 */
+#define LBMPC_VERSION 110 /* 0.1.1 */
 
 /* usage errors */
 #define LBMPC_ERR_ARG (-1)         /* null pointer / negative size / inconsistent dims      */
@@ -55,7 +59,13 @@ extern "C" {
 #define LBMPC_MAX_S 64   /* terms of the Minkowski sum            */
 
 int lbmpc_version(void);
-/* Select device `device`, check it is gfx950. Must be called once per process before anything else. */
+/* Validate a device (it must be gfx950) before anything else runs on it.  device >= 0: select it for the calling
+ * thread (hipSetDevice) and validate it; LBMPC_DEVICE_CURRENT: validate the calling thread's current device without
+ * changing the selection (one process per GPU under a launcher that has already bound the device).  Call it once per
+ * device used.  Entry points without a context run on the calling thread's current device; entry points that take
+ * a context run on the device the context was created on, whatever the caller has selected (the caller's selection
+ * is restored on return). */
+#define LBMPC_DEVICE_CURRENT (-1)
 int lbmpc_init(int device);
 /* Text of the last HIP/usage error on this thread (static storage). */
 const char* lbmpc_last_error(void);
@@ -234,7 +244,6 @@ typedef struct lbmpc_mc_cfg {
     const double* x0;     /* nx: initial relative state x_RM_0 (same for all trials)       */
     double acc_bound;     /* |u| bound of the violation test, Case_5...:90-91              */
     double distance_error;/* state bound of the violation test, Case_5...:92-93            */
-    double vol_W;         /* volume of the prior W (vol(W_hat) = alpha^nx vol_W)           */
     int32_t traj_trials;  /* record full trajectories for the first traj_trials trials     */
     int32_t sampler_max_attempts; /* 1000 in ModelingCar.m:54                              */
 } lbmpc_mc_cfg;

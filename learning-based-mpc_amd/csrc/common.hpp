@@ -14,7 +14,21 @@ namespace lbmpc {
 
 // ---- host-side error plumbing -----------------------------------------------------------------
 void set_error(const char* fmt, ...);
-int check_device();  // 0 if lbmpc_init succeeded on this process, else LBMPC_ERR_NODEVICE
+int check_device();        // 0 if lbmpc_init validated the calling thread's current device, else LBMPC_ERR_NODEVICE
+int check_any_device();    // 0 if lbmpc_init validated some device (entry points that take a context)
+int device_ready(int device);  // lbmpc_init validated `device`
+
+// Makes `device` current for the lifetime of the object and restores the caller's device afterwards
+// (entry points that take a context run on the context's device whatever the caller had selected).
+class DeviceGuard {
+public:
+    explicit DeviceGuard(int device);
+    ~DeviceGuard();
+    int rc() const { return rc_; }  // 0 or LBMPC_ERR_HIP (message set)
+private:
+    int prev_ = -1, rc_ = 0;
+    bool switched_ = false;
+};
 
 #define LB_HIP(expr)                                                                      \
     do {                                                                                  \

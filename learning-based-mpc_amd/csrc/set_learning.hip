@@ -178,32 +178,28 @@ static void plan_chunks(int64_t N, int64_t batch, int spl, int* chunks, int64_t*
 
 using namespace lbmpc;
 
-// An information set split over several waves (chunks > 1) leaves partial maxima in a stream-ordered scratch buffer
-// (hipMallocAsync / hipFreeAsync on the caller's stream: no synchronisation), folded by finish_max_kernel.
-extern "C" int lbmpc_halfspace_max_dev(const double* WA, int nW, int nx, const double* samples_dev, int64_t N,
-                                       int64_t batch, int64_t batch_stride, double* m_out_dev, void* stream) {
-    if (int rc = check_device()) return rc;
+// Shared body of lbmpc_halfspace_max_dev / lbmpc_halfspace_max_noalloc: `part` receives the per-(set, chunk) partial
+// maxima when the plan splits sets over several waves (units * nW doubles), else the kernel writes m_out directly.
+static int hmax_validate(const double* WA, int nW, int nx, const double* samples_dev, int64_t N, int64_t batch,
+                         int64_t batch_stride, double* m_out_dev) {
     if (!WA || !samples_dev || !m_out_dev || N < 1 || batch < 0 || nW < 1 || nx < 1) {
         set_error("lbmpc_halfspace_max: bad argument");
         return LBMPC_ERR_ARG;
     }
     if (nx > LBMPC_MAX_NX || nW > LBMPC_MAX_NW) { set_error("lbmpc_halfspace_max: nx<=%d, nW<=%d", LBMPC_MAX_NX, LBMPC_MAX_NW); return LBMPC_ERR_DIM; }
     if (batch > 1 && batch_stride < N * nx) { set_error("lbmpc_halfspace_max: batch_stride < N*nx"); return LBMPC_ERR_ARG; }
-    if (batch == 0) return 0;
-    hipStream_t st = (hipStream_t)stream;
+    return 0;
+}
+static int hmax_spl(int nx) { return (nx == 1) ? 2 : (nx == 3 ? 2 : 1); }
+
+static int hmax_launch(const double* WA, int nW, int nx, const double* samples_dev, int64_t N, int64_t batch,
+                       int64_t batch_stride, double* m_out_dev, int chunks, int64_t spc, double* part_buf,
+                       hipStream_t st) {
     RowsW W;
     pack_rows(WA, nW, nx, &W);
-    const int spl = (nx == 1) ? 2 : (nx == 3 ? 2 : 1);
-    int chunks; int64_t spc;
-    plan_chunks(N, batch, spl, &chunks, &spc);
     const int64_t units = batch * chunks;
     dim3 grid((unsigned)((units + 3) / 4));
-    double* part = m_out_dev;
-    void* tmp = nullptr;
-    if (chunks > 1) {
-        LB_HIP(hipMallocAsync(&tmp, sizeof(double) * units * nW, st));
-        part = (double*)tmp;
-    }
+    double* part = chunks > 1 ? part_buf : m_out_dev;
     const bool vec = ((uintptr_t)samples_dev % 16 == 0) && ((batch_stride * 8) % 16 == 0 || batch == 1);
     const bool boxrows = (nW == 2 * nx);
     if (boxrows && nx == 1) launch_hmax<1, 2, 2>(vec, grid, st, samples_dev, N, batch, batch_stride, chunks, spc, W, part);
@@ -221,12 +217,28 @@ extern "C" int lbmpc_halfspace_max_dev(const double* WA, int nW, int nx, const d
     }
     LB_HIP(hipGetLastError());
     if (chunks > 1) {
-        int64_t n = batch * nW;
+        const int64_t n = batch * nW;
         hipLaunchKernelGGL(finish_max_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, batch, chunks, nW, m_out_dev);
         LB_HIP(hipGetLastError());
-        LB_HIP(hipFreeAsync(tmp, st));
     }
     return 0;
+}
+
+// An information set split over several waves (chunks > 1) leaves partial maxima in a stream-ordered scratch buffer
+// (hipMallocAsync / hipFreeAsync on the caller's stream: no synchronisation), folded by finish_max_kernel.
+extern "C" int lbmpc_halfspace_max_dev(const double* WA, int nW, int nx, const double* samples_dev, int64_t N,
+                                       int64_t batch, int64_t batch_stride, double* m_out_dev, void* stream) {
+    if (int rc = check_device()) return rc;
+    if (int rc = hmax_validate(WA, nW, nx, samples_dev, N, batch, batch_stride, m_out_dev)) return rc;
+    if (batch == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    int chunks; int64_t spc;
+    plan_chunks(N, batch, hmax_spl(nx), &chunks, &spc);
+    void* tmp = nullptr;
+    if (chunks > 1) LB_HIP(hipMallocAsync(&tmp, sizeof(double) * batch * chunks * nW, st));
+    const int rc = hmax_launch(WA, nW, nx, samples_dev, N, batch, batch_stride, m_out_dev, chunks, spc, (double*)tmp, st);
+    if (tmp) LB_HIP(hipFreeAsync(tmp, st));
+    return rc;
 }
 
 extern "C" int lbmpc_halfspace_max(const double* WA, int nW, int nx, const double* samples, int64_t N,

@@ -118,6 +118,72 @@ static int launch_support(const double* Gdev, int nx, int s, int nV, double scal
     return 0;
 }
 
+// Device copies of the stacked rows G, kept per (device, contents): repeated sweeps with the same (A, V_W, s) -- the
+// usual pattern, e.g. a direction batch per solver call -- skip the allocation and the copy (which cost twice the
+// kernel's time at 1M directions).  A small LRU per process (SUPPORT_CACHE entries over all devices), so that callers
+// that alternate between a few parameter sets (3x3 / 4x4, transpose on/off, one host thread per device) do not thrash
+// it.  A miss allocates (hipMalloc) and uploads stream-ordered from the entry's own host copy, which outlives the
+// launch; only the eviction of the least recently used entry (more than SUPPORT_CACHE live parameter sets) waits for
+// the device (hipFree).  Hits enqueue asynchronously and never synchronise.
+struct RowsEntry {
+    int device = -1;
+    std::vector<double> host;
+    void* dev = nullptr;
+    hipEvent_t ready = nullptr;   // recorded after the upload: launches on other streams wait for it
+    hipStream_t upload_stream = nullptr;
+    uint64_t stamp = 0;
+};
+static const int SUPPORT_CACHE = 8;
+
+static void drop_entry(RowsEntry& e) {
+    if (!e.dev) return;
+    DeviceGuard g(e.device);
+    (void)hipFree(e.dev);   // waits for the launches that still read these rows
+    if (e.ready) (void)hipEventDestroy(e.ready);
+    e.dev = nullptr; e.ready = nullptr; e.host.clear();
+}
+
+static int cached_rows(const std::vector<double>& G, hipStream_t st, const double** out) {
+    static std::mutex mu;
+    static RowsEntry cache[SUPPORT_CACHE];
+    static uint64_t clock_ = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    int device = 0;
+    LB_HIP(hipGetDevice(&device));
+    for (RowsEntry& e : cache)
+        if (e.dev && e.device == device && e.host == G) {
+            e.stamp = ++clock_;
+            if (st != e.upload_stream) LB_HIP(hipStreamWaitEvent(st, e.ready, 0));
+            *out = (const double*)e.dev;
+            return 0;
+        }
+    RowsEntry* slot = nullptr;
+    for (RowsEntry& e : cache) if (!e.dev) { slot = &e; break; }
+    if (!slot) {
+        slot = &cache[0];
+        for (RowsEntry& e : cache) if (e.stamp < slot->stamp) slot = &e;
+        drop_entry(*slot);
+    }
+    RowsEntry& e = *slot;
+    LB_HIP(hipMalloc(&e.dev, G.size() * 8));
+    e.host = G; e.device = device; e.stamp = ++clock_; e.upload_stream = st;
+    hipError_t err = hipEventCreateWithFlags(&e.ready, hipEventDisableTiming);
+    if (err == hipSuccess) err = hipMemcpyAsync(e.dev, e.host.data(), G.size() * 8, hipMemcpyHostToDevice, st);
+    if (err == hipSuccess) err = hipEventRecord(e.ready, st);
+    if (err != hipSuccess) {
+        drop_entry(e);
+        set_error("support: upload of the stacked rows -> %s", hipGetErrorString(err));
+        return LBMPC_ERR_HIP;
+    }
+    *out = (const double*)e.dev;
+    return 0;
+}
+
+static int check_alpha(double alpha) {
+    if (!(alpha >= 0.0 && alpha < 1.0)) { set_error("support: alpha = %g outside [0, 1) (the scale 1/(1-alpha) would be infinite or negative)", alpha); return LBMPC_ERR_ARG; }
+    return 0;
+}
+
 static int check_support_args(const double* A, int nx, const double* Vw, int nV, int s) {
     if (!A || !Vw || nx < 1 || nV < 1 || s < 1) { set_error("support: bad argument"); return LBMPC_ERR_ARG; }
     if (nx > LBMPC_MAX_NX || nV > LBMPC_MAX_NV || s > LBMPC_MAX_S || (int64_t)s * nV > 2048) {
@@ -136,35 +202,22 @@ extern "C" int lbmpc_support_batch_dev(const double* A, int nx, const double* Vw
                                        void* stream) {
     if (int rc = check_device()) return rc;
     if (int rc = check_support_args(A, nx, Vw, nV, s)) return rc;
+    if (int rc = check_alpha(alpha)) return rc;
     if (!D_dev || !h_out_dev || nd < 0) { set_error("lbmpc_support_batch: bad argument"); return LBMPC_ERR_ARG; }
     if (nd == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     std::vector<double> G;
     stack_G(A, nx, Vw, nV, s, transpose_flag, G);
-    // The stacked G of the last call stays on its device: repeated sweeps with the same (A, V_W, s) -- the usual
-    // pattern, e.g. the s/alpha loop or a direction batch per solver call -- skip the allocation, the copy and the
-    // synchronisation (which cost twice the kernel's time at 1M directions).  One entry per process, guarded.
-    static std::mutex mu;
-    static std::vector<double> cachedG;
-    static void* cachedDev = nullptr;
-    static int cachedDevice = -1;
-    std::lock_guard<std::mutex> lock(mu);
-    int device = 0;
-    LB_HIP(hipGetDevice(&device));
-    if (!(cachedDev && cachedDevice == device && cachedG == G)) {
-        LB_HIP(hipDeviceSynchronize());  // earlier launches may still read the previous entry
-        if (cachedDev) { (void)hipFree(cachedDev); cachedDev = nullptr; cachedG.clear(); }
-        LB_HIP(hipMalloc(&cachedDev, G.size() * 8));
-        LB_HIP(hipMemcpy(cachedDev, G.data(), G.size() * 8, hipMemcpyHostToDevice));
-        cachedG = G; cachedDevice = device;
-    }
-    return launch_support((const double*)cachedDev, nx, s, nV, 1.0 / (1.0 - alpha), D_dev, nd, h_out_dev, st);
+    const double* Gdev = nullptr;
+    if (int rc = cached_rows(G, st, &Gdev)) return rc;
+    return launch_support(Gdev, nx, s, nV, 1.0 / (1.0 - alpha), D_dev, nd, h_out_dev, st);
 }
 
 extern "C" int lbmpc_support_batch(const double* A, int nx, const double* Vw, int nV, int s, double alpha,
                                    const double* D, int64_t nd, int transpose_flag, double* h_out) {
     if (int rc = check_device()) return rc;
     if (int rc = check_support_args(A, nx, Vw, nV, s)) return rc;
+    if (int rc = check_alpha(alpha)) return rc;
     if (!D || !h_out || nd < 0) { set_error("lbmpc_support_batch: bad argument"); return LBMPC_ERR_ARG; }
     if (nd == 0) return 0;
     DevBuf dD, dh;

@@ -1145,6 +1145,7 @@ static void inscribed_ellipsoid(int nx, int nS, const double* S_A /* col-major *
 
 extern "C" void lbmpc_destroy(lbmpc_ctx* c) {
     if (!c) return;
+    DeviceGuard guard(c->device);
     if (c->d) (void)hipFree(c->d);
     if (c->dS) (void)hipFree(c->dS);
     if (c->dH) (void)hipFree(c->dH);
@@ -1243,7 +1244,7 @@ extern "C" int lbmpc_uqmpc_create(const lbmpc_params* p, lbmpc_ctx** out) {
     }
     for (int k = 0; k < LBMPC_MAX_NZ; ++k) h.cmH[k] = 0.0;
     for (int r = 0; r < nH; ++r) for (int k = 0; k < nz; ++k) h.cmH[k] = std::max(h.cmH[k], std::fabs(Hm[(size_t)r * h.nzp + k]));
-    (void)hipGetDevice(&c->device);
+    if (hipGetDevice(&c->device) != hipSuccess) { set_error("lbmpc_uqmpc_create: hipGetDevice failed"); delete c; return LBMPC_ERR_HIP; }
     auto fail = [&](hipError_t e, const char* what) { set_error("lbmpc_uqmpc_create: %s -> %s", what, hipGetErrorString(e)); lbmpc_destroy(c); return LBMPC_ERR_HIP; };
     hipError_t e;
     if ((e = hipMalloc((void**)&c->dS, Srow.size() * 8)) != hipSuccess) return fail(e, "hipMalloc");
@@ -1308,9 +1309,11 @@ extern "C" int lbmpc_uqmpc_step(lbmpc_ctx* c, int64_t batch, int uq_update, cons
                                 const double* v_prev, const double* w_new, double* s0, double* cc, double* u,
                                 double* alpha, double* v, double* hk, double* Sb_hat, double* Wb_hat, int* status,
                                 int* n_active, int* active_set, int* qp_iters) {
-    if (int rc = check_device()) return rc;
+    if (int rc = check_any_device()) return rc;
     if (!c || !x || !alpha_prev || !v_prev || (uq_update && !w_new) || batch < 0) { set_error("lbmpc_uqmpc_step: bad argument"); return LBMPC_ERR_ARG; }
     if (batch == 0) return 0;
+    DeviceGuard guard(c->device);
+    if (guard.rc()) return guard.rc();
     const CtxDev& h = c->h;
     const size_t B = (size_t)batch;
     const int ncv = h.nz - h.nx;
@@ -1339,8 +1342,10 @@ extern "C" int lbmpc_uqmpc_step(lbmpc_ctx* c, int64_t batch, int uq_update, cons
 
 extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lbmpc_mc_cfg* cfg, lbmpc_mc_out* out,
                                 void* stream) {
-    if (int rc = check_device()) return rc;
+    if (int rc = check_any_device()) return rc;
     if (!c || !smp || !cfg || !out || !cfg->x0) { set_error("lbmpc_mc_run: null argument"); return LBMPC_ERR_ARG; }
+    DeviceGuard guard(c->device);
+    if (guard.rc()) return guard.rc();
     if (cfg->trials < 0 || cfg->steps < 0 || cfg->card_I0 < 1 || cfg->sampler_max_attempts < 1 || cfg->traj_trials < 0) { set_error("lbmpc_mc_run: bad configuration"); return LBMPC_ERR_ARG; }
     SamplerDev sd;
     if (int rc = pack_sampler(smp, &sd)) return rc;
@@ -1493,19 +1498,23 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
 }
 
 extern "C" int lbmpc_mc_counters(lbmpc_ctx* c, uint64_t* out8) {
-    if (int rc = check_device()) return rc;
+    if (int rc = check_any_device()) return rc;
     if (!c || !out8) { set_error("lbmpc_mc_counters: null argument"); return LBMPC_ERR_ARG; }
     for (int i = 0; i < 8; ++i) out8[i] = 0;
     if (!c->counters) return 0;
+    DeviceGuard guard(c->device);
+    if (guard.rc()) return guard.rc();
     LB_HIP(hipDeviceSynchronize());
     LB_HIP(hipMemcpy(out8, c->counters, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return 0;
 }
 
 extern "C" int lbmpc_mc_run(lbmpc_ctx* c, const lbmpc_sampler* smp, const lbmpc_mc_cfg* cfg, lbmpc_mc_out* out) {
-    if (int rc = check_device()) return rc;
+    if (int rc = check_any_device()) return rc;
     if (!c || !cfg || !out) { set_error("lbmpc_mc_run: null argument"); return LBMPC_ERR_ARG; }
     if (cfg->trials < 0 || cfg->steps < 0 || cfg->traj_trials < 0) { set_error("lbmpc_mc_run: bad configuration"); return LBMPC_ERR_ARG; }
+    DeviceGuard guard(c->device);
+    if (guard.rc()) return guard.rc();
     const size_t Tn = (size_t)cfg->trials, nx = c->h.nx, nu = c->h.nu, K = (size_t)cfg->steps;
     const size_t R = (size_t)(cfg->traj_trials < cfg->trials ? cfg->traj_trials : cfg->trials);
     struct Out { void* host; size_t bytes; DevBuf buf; };

@@ -19,6 +19,7 @@ ERR_ARG, ERR_DIM, ERR_HIP, ERR_UNSUPPORTED, ERR_NODEVICE = -1, -2, -3, -4, -5
 ST_OK, ST_QP_INFEASIBLE, ST_LP_INFEASIBLE, ST_ITER_CAP, ST_SAMPLER_CAP = 0, 1, 2, 3, 4
 MS_MAX_LITERAL, MS_SUM_LITERAL, MS_RAKOVIC = 0, 1, 2
 TIE_CENTER = 1
+DEVICE_CURRENT = -1
 
 
 class Sampler(C.Structure):
@@ -39,7 +40,7 @@ class Params(C.Structure):
 class McCfg(C.Structure):
     _fields_ = [("trials", C.c_int64), ("trial0", C.c_int64), ("steps", C.c_int32), ("card_I0", C.c_int32),
                 ("seed", C.c_uint64), ("x0", c_double_p), ("acc_bound", C.c_double),
-                ("distance_error", C.c_double), ("vol_W", C.c_double), ("traj_trials", C.c_int32),
+                ("distance_error", C.c_double), ("traj_trials", C.c_int32),
                 ("sampler_max_attempts", C.c_int32)]
 
 

@@ -87,6 +87,11 @@ def MRPISet(Ak, W, epsilon, template_directions=None, mode=_abi.MS_MAX_LITERAL, 
     rng = np.random.default_rng(seed)
     WV = W.vertices()
     s, alpha, Ms, rc = core.mrpi_s_alpha(Ak, WV, W.A, W.b, reference_directions(nx, rng).T, epsilon, mode=mode)
+    if rc != 0 or not (0.0 <= alpha < 1.0):
+        # the reference loops for ever in this case (MRPISet.m:27 has no cap); a set built from an (s, alpha) that
+        # still violates the loop condition is not an outer approximation of anything
+        raise RuntimeError(f"MRPISet: the (s, alpha) search stopped with status {rc} at s={s}, alpha={alpha:g} "
+                           f"(Ak not contractive enough for epsilon={epsilon}?)")
     if template_directions is None:
         n = {1: 2, 2: 128, 3: 795, 4: 1644}.get(nx, 1644)
         D = rng.normal(size=(n, nx))

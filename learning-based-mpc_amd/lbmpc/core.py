@@ -17,16 +17,14 @@ class LbmpcError(RuntimeError):
         self.code = code
 
 
-_inited = {}
-
-
-def init(device=0):
+def init(device=None):
+    """Validate a device for the library.  device=None: the calling thread's CURRENT device, left selected as it is
+    (what every wrapper below uses: under one process per GPU the launcher has already bound the device, and the
+    library must never fall back to device 0 behind it).  An explicit index selects that device first."""
     lib = _abi.load()
-    if not _inited.get(device):
-        rc = lib.lbmpc_init(int(device))
-        if rc != 0:
-            raise LbmpcError(rc, "lbmpc_init")
-        _inited[device] = True
+    rc = lib.lbmpc_init(_abi.DEVICE_CURRENT if device is None else int(device))
+    if rc != 0:
+        raise LbmpcError(rc, "lbmpc_init")
     return lib
 
 
@@ -109,8 +107,9 @@ def homothety_lp(WA, Wb, m):
 class Context:
     """Device-resident controller constants (lbmpc_uqmpc_create / lbmpc_destroy)."""
 
-    def __init__(self, params_dict):
-        self.lib = init()
+    def __init__(self, params_dict, device=None):
+        """device=None: the current device.  The context remembers its device; every later call runs there."""
+        self.lib = init(device)
         self.d = params_dict
         self.keep = _abi.make_params(params_dict)
         self.handle = C.c_void_p()
@@ -166,7 +165,7 @@ class Context:
         return {n: int(buf[i]) for i, n in enumerate(names)}
 
     def mc_run(self, sampler, trials, steps, card_I0, seed, x0, acc_bound, distance_error, trial0=0, traj_trials=0,
-               sampler_max_attempts=1000, vol_W=0.0):
+               sampler_max_attempts=1000):
         """Batched closed-loop Monte-Carlo (Case_3/4/5 loops); returns host arrays."""
         nx, nu = self.nx, self.nu
         x0 = fcol(x0).ravel()
@@ -176,7 +175,7 @@ class Context:
                  alpha0=np.zeros(trials), x_final=np.zeros((trials, nx)), traj_x=np.zeros((R, steps + 1, nx)),
                  traj_u=np.zeros((R, steps, nu)), traj_alpha=np.zeros((R, steps + 1)), traj_s0=np.zeros((R, steps, nx)))
         cfg = _abi.McCfg(trials=trials, trial0=trial0, steps=steps, card_I0=card_I0, seed=seed, x0=dptr(x0),
-                         acc_bound=float(acc_bound), distance_error=float(distance_error), vol_W=float(vol_W),
+                         acc_bound=float(acc_bound), distance_error=float(distance_error),
                          traj_trials=R, sampler_max_attempts=sampler_max_attempts)
         out = _abi.McOut(**{k: (v.ctypes.data_as(_abi.c_int32_p) if v.dtype == np.int32 else dptr(v))
                             for k, v in o.items()})

@@ -20,7 +20,7 @@ def _f64(t):
 
 def halfspace_max(WA, samples, out=None):
     """samples: CUDA fp64 tensor [batch, N, nx] (each set column-major nx x N) -> m [batch, nW]"""
-    lib = core.init(torch.cuda.current_device())
+    lib = core.init()
     WA = fcol(WA)
     nW, nx = WA.shape
     batch, N, nx2 = samples.shape
@@ -33,7 +33,7 @@ def halfspace_max(WA, samples, out=None):
 
 
 def homothety_lp(WA, Wb, m, alpha=None, v=None):
-    lib = core.init(torch.cuda.current_device())
+    lib = core.init()
     WA, Wb = fcol(WA), fcol(Wb).ravel()
     nW, nx = WA.shape
     batch = m.shape[0]
@@ -45,7 +45,7 @@ def homothety_lp(WA, Wb, m, alpha=None, v=None):
 
 
 def sample_information_sets(sampler, WA, N, batch, seed, set0=0, max_attempts=100, samples=None, m=None):
-    lib = core.init(torch.cuda.current_device())
+    lib = core.init()
     WA = fcol(WA)
     nW, nx = WA.shape
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -58,7 +58,7 @@ def sample_information_sets(sampler, WA, N, batch, seed, set0=0, max_attempts=10
 
 def support_batch(A, Vw, s, alpha, D, transpose=True, out=None):
     """D: CUDA fp64 tensor [nd, nx] (column-major nx x nd) -> h [nd]"""
-    lib = core.init(torch.cuda.current_device())
+    lib = core.init()
     A, Vw = fcol(A), fcol(Vw)
     nd, nx = D.shape
     out = torch.empty(nd, dtype=torch.float64, device=D.device) if out is None else out
@@ -90,7 +90,7 @@ def mc_run(ctx, sampler, bufs, steps, card_I0, seed, x0, acc_bound, distance_err
            sampler_max_attempts=1000):
     x0 = fcol(x0).ravel()
     cfg = _abi.McCfg(trials=bufs.trials, trial0=trial0, steps=steps, card_I0=card_I0, seed=seed, x0=dptr(x0),
-                     acc_bound=float(acc_bound), distance_error=float(distance_error), vol_W=0.0, traj_trials=0,
+                     acc_bound=float(acc_bound), distance_error=float(distance_error), traj_trials=0,
                      sampler_max_attempts=sampler_max_attempts)
     core._chk(ctx.lib.lbmpc_mc_run_dev(ctx.handle, sampler.ref(), C.byref(cfg), C.byref(bufs.struct), _stream()),
               "lbmpc_mc_run_dev")

@@ -114,7 +114,7 @@ class Context:
         return o
 
     def mc_run(self, sampler, trials, steps, card_I0, seed, x0, acc_bound, distance_error, trial0=0, traj_trials=0,
-               sampler_max_attempts=1000, vol_W=0.0):
+               sampler_max_attempts=1000):
         nx, nu = self.nx, self.nu
         x0 = fcol(x0).ravel()
         R = min(traj_trials, trials)
@@ -123,7 +123,7 @@ class Context:
                  alpha0=np.zeros(trials), x_final=np.zeros((trials, nx)), traj_x=np.zeros((R, steps + 1, nx)),
                  traj_u=np.zeros((R, steps, nu)), traj_alpha=np.zeros((R, steps + 1)), traj_s0=np.zeros((R, steps, nx)))
         cfg = _abi.McCfg(trials=trials, trial0=trial0, steps=steps, card_I0=card_I0, seed=seed, x0=dptr(x0),
-                         acc_bound=float(acc_bound), distance_error=float(distance_error), vol_W=float(vol_W),
+                         acc_bound=float(acc_bound), distance_error=float(distance_error),
                          traj_trials=R, sampler_max_attempts=sampler_max_attempts)
         out = _abi.McOut(**{k: (v.ctypes.data_as(_abi.c_int32_p) if v.dtype == np.int32 else dptr(v))
                             for k, v in o.items()})

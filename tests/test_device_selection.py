@@ -1,0 +1,70 @@
+"""Device selection of the host wrappers (round-1 advisor finding: every wrapper used to call lbmpc_init(0), which
+re-selected GPU 0 on ranks whose launcher had bound another GPU).  CPU part: with the library's entry points replaced
+by recorders, core.init(1) followed by Context(P) and every core.* wrapper must never ask for device 0.  GPU part: a
+context created on cuda:1 runs on cuda:1 whatever device is current (skipped on a one-GPU box)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import fixtures
+from lbmpc import _abi, core
+
+
+class _Recorder:
+    """stands in for the CDLL: records lbmpc_init's argument, pretends every other call succeeded"""
+
+    def __init__(self):
+        self.init_args = []
+
+    def lbmpc_init(self, d):
+        self.init_args.append(int(d))
+        return 0
+
+    def lbmpc_last_error(self):
+        return b""
+
+    def __getattr__(self, name):
+        if name.startswith("lbmpc_"):
+            return lambda *a: 0
+        raise AttributeError(name)
+
+
+def test_wrappers_never_select_device_0_implicitly(monkeypatch):
+    rec = _Recorder()
+    monkeypatch.setattr(_abi, "_lib", rec)
+    P = fixtures.params_dict()
+    core.init(1)                      # what a rank bound to GPU 1 does first
+    ctx = core.Context(P)             # used to call lbmpc_init(0)
+    core.halfspace_max(P["W_A"], np.zeros((2, 8)))
+    core.homothety_lp(P["W_A"], P["W_b"], np.zeros(4))
+    core.support_batch(np.eye(2), P["W_V"], 1, 0.0, np.eye(2))
+    ctx.handle = C.c_void_p()         # nothing to destroy
+    assert rec.init_args[0] == 1
+    assert all(d == _abi.DEVICE_CURRENT for d in rec.init_args[1:]), rec.init_args
+    assert 0 not in rec.init_args
+    ctx2 = core.Context(P, device=3)  # an explicit device is passed through
+    ctx2.handle = C.c_void_p()
+    assert rec.init_args[-1] == 3
+
+
+@pytest.mark.gpu
+def test_context_runs_on_its_own_device():
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import oracle_core
+    P = fixtures.params_dict()
+    smp = _abi.make_sampler(**fixtures.sampler_args(P))
+    kw = dict(trials=130, steps=6, card_I0=10, seed=9, x0=[-12.0, 5.0], acc_bound=2.0, distance_error=15.0)
+    torch.cuda.set_device(1)
+    core.init()                        # adopts cuda:1
+    ctx1 = core.Context(P)
+    torch.cuda.set_device(0)           # caller moves on; the context must still run on cuda:1
+    core.init()
+    g = ctx1.mc_run(smp, **kw)
+    assert torch.cuda.current_device() == 0      # the caller's selection is restored
+    o = oracle_core.Context(P).mc_run(smp, **kw)
+    for k in ("infeasible", "status", "qp_iters"):
+        np.testing.assert_array_equal(g[k], o[k], err_msg=k)
+    ctx1.close()
