@@ -113,6 +113,20 @@ int lbmpc_halfspace_max(const double* WA, int nW, int nx, const double* samples,
 int lbmpc_halfspace_max_dev(const double* WA, int nW, int nx, const double* samples_dev, int64_t N,
                             int64_t batch, int64_t batch_stride, double* m_out_dev, void* stream);
 
+/* The same reduction for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc): device pointers and a stream as lbmpc_halfspace_max_dev, but the partial maxima of sets
+ * that are split over several waves live in a static device array of LBMPC_NOALLOC_MAX_PARTIALS doubles (2 MiB,
+ * held by every GPU the library runs on until the process ends) instead of a hipMallocAsync buffer.  No counterpart
+ * in the reference (MATLAB has no such constraint).  Calls no hipMalloc / hipFree / allocating routine.
+ * The library splits a set over `chunks` waves when batch < 16384 (chunks = min(ceil(16384 / batch),
+ * ceil(N / (256 * spl))), spl = 2 for nx in {1, 3} else 1); a call with chunks > 1 and batch * chunks * nW >
+ * LBMPC_NOALLOC_MAX_PARTIALS returns LBMPC_ERR_DIM (split the batch).  Results are bit-identical to
+ * lbmpc_halfspace_max_dev.  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams,
+ * two threads) race; serialise them. */
+#define LBMPC_NOALLOC_MAX_PARTIALS 262144
+int lbmpc_halfspace_max_noalloc(const double* WA, int nW, int nx, const double* samples_dev, int64_t N,
+                                int64_t batch, int64_t batch_stride, double* m_out_dev, void* stream);
+
 /* Sampler description: w = xi_EV - xi_LV - B*u_LV with xi_* uniform on {x: Xi_A x <= Xi_b} by
  * rejection from the bounding box [lo, hi] of the vertices, u_LV ~ U[min_u, max_u].
  * Optional oriented proposal box: with EV_U / LV_U (nx x nx, column-major, invertible) the candidate is x = U t,

@@ -17,6 +17,7 @@ void set_error(const char* fmt, ...);
 int check_device();        // 0 if lbmpc_init validated the calling thread's current device, else LBMPC_ERR_NODEVICE
 int check_any_device();    // 0 if lbmpc_init validated some device (entry points that take a context)
 int device_ready(int device);  // lbmpc_init validated `device`
+int resolve_noalloc_scratch(int device);  // set_learning.hip: device address of the static scratch array on `device` (current)
 
 // Makes `device` current for the lifetime of the object and restores the caller's device afterwards
 // (entry points that take a context run on the context's device whatever the caller had selected).

@@ -83,6 +83,7 @@ extern "C" int lbmpc_init(int device) {
         lbmpc::set_error("lbmpc_init: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
         return LBMPC_ERR_NODEVICE;
     }
+    if (int rc = lbmpc::resolve_noalloc_scratch(device)) return rc;   // per-device address of the static scratch array
     lbmpc::g_ready_mask.fetch_or((uint64_t)1 << device);
     return 0;
 }

@@ -241,6 +241,50 @@ extern "C" int lbmpc_halfspace_max_dev(const double* WA, int nW, int nx, const d
     return rc;
 }
 
+// ---- allocation-free variant (no counterpart in the reference; see include/lbmpc.h) --------------------------------
+// Same kernels, same chunk plan and therefore the same partition of the work as lbmpc_halfspace_max_dev; the partial
+// maxima of sets split over several waves go to a file-scope device array instead of a hipMallocAsync buffer.  Every
+// GPU holds its own copy of the array at its own address: the address is resolved once per device by
+// resolve_noalloc_scratch (called from lbmpc_init with that device current) and host code only ever uses that pointer.
+// Nothing in the array has to start at zero: every partial a launch reads was written by that launch's first kernel.
+static __device__ __align__(256) double scratch[LBMPC_NOALLOC_MAX_PARTIALS];
+static double* g_scratch_ptr[64];   // per device: device address of `scratch` on that GPU (nullptr: not resolved)
+
+namespace lbmpc {
+int resolve_noalloc_scratch(int device /* current on the calling thread */) {
+    if (device < 0 || device >= 64) { set_error("resolve_noalloc_scratch: device %d out of range", device); return LBMPC_ERR_ARG; }
+    if (g_scratch_ptr[device]) return 0;
+    double* ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) {
+        set_error("hipGetSymbolAddress(scratch) on device %d -> %s", device, hipGetErrorString(e));
+        return LBMPC_ERR_HIP;
+    }
+    g_scratch_ptr[device] = ptr;
+    return 0;
+}
+}  // namespace lbmpc
+
+extern "C" int lbmpc_halfspace_max_noalloc(const double* WA, int nW, int nx, const double* samples_dev, int64_t N,
+                                           int64_t batch, int64_t batch_stride, double* m_out_dev, void* stream) {
+    if (int rc = check_device()) return rc;
+    if (int rc = hmax_validate(WA, nW, nx, samples_dev, N, batch, batch_stride, m_out_dev)) return rc;
+    if (batch == 0) return 0;
+    int device = -1;
+    LB_HIP(hipGetDevice(&device));
+    double* ptr = (device >= 0 && device < 64) ? g_scratch_ptr[device] : nullptr;
+    if (!ptr) { set_error("lbmpc_halfspace_max_noalloc: scratch of device %d was not resolved by lbmpc_init", device); return LBMPC_ERR_NODEVICE; }
+    int chunks; int64_t spc;
+    plan_chunks(N, batch, hmax_spl(nx), &chunks, &spc);
+    if (chunks > 1 && batch * chunks * nW > (int64_t)LBMPC_NOALLOC_MAX_PARTIALS) {
+        set_error("lbmpc_halfspace_max_noalloc: %lld sets x %d chunks x %d rows = %lld partial maxima exceed the static scratch "
+                  "(LBMPC_NOALLOC_MAX_PARTIALS = %d doubles); split the batch or use lbmpc_halfspace_max_dev",
+                  (long long)batch, chunks, nW, (long long)(batch * chunks * nW), (int)LBMPC_NOALLOC_MAX_PARTIALS);
+        return LBMPC_ERR_DIM;
+    }
+    return hmax_launch(WA, nW, nx, samples_dev, N, batch, batch_stride, m_out_dev, chunks, spc, ptr, (hipStream_t)stream);
+}
+
 extern "C" int lbmpc_halfspace_max(const double* WA, int nW, int nx, const double* samples, int64_t N,
                                    int64_t batch, int64_t batch_stride, double* m_out) {
     if (int rc = check_device()) return rc;

@@ -20,6 +20,7 @@ ST_OK, ST_QP_INFEASIBLE, ST_LP_INFEASIBLE, ST_ITER_CAP, ST_SAMPLER_CAP = 0, 1, 2
 MS_MAX_LITERAL, MS_SUM_LITERAL, MS_RAKOVIC = 0, 1, 2
 TIE_CENTER = 1
 DEVICE_CURRENT = -1
+NOALLOC_MAX_PARTIALS = 262144
 
 
 class Sampler(C.Structure):
@@ -154,6 +155,7 @@ def declare(lib, prefix):
         for name in ["support_batch", "halfspace_max", "sample_information_sets", "homothety_lp", "mc_run"]:
             f = getattr(lib, prefix + name + "_dev")
             f.argtypes, f.restype = sig[name] + [vp], ci
+        lib.lbmpc_halfspace_max_noalloc.argtypes, lib.lbmpc_halfspace_max_noalloc.restype = sig["halfspace_max"] + [vp], ci
         lib.lbmpc_mc_counters.argtypes, lib.lbmpc_mc_counters.restype = [vp, C.POINTER(C.c_uint64)], ci
         lib.lbmpc_version.restype = ci
         lib.lbmpc_init.argtypes, lib.lbmpc_init.restype = [ci], ci

@@ -32,6 +32,18 @@ def halfspace_max(WA, samples, out=None):
     return out
 
 
+def halfspace_max_noalloc(WA, samples, out):
+    """lbmpc_halfspace_max_noalloc: as halfspace_max, but `out` is mandatory and the library allocates nothing"""
+    lib = core.init()
+    WA = fcol(WA)
+    nW, nx = WA.shape
+    batch, N, nx2 = samples.shape
+    assert nx2 == nx and out.shape == (batch, nW)
+    core._chk(lib.lbmpc_halfspace_max_noalloc(dptr(WA), nW, nx, _f64(samples), N, batch, N * nx, _f64(out), _stream()),
+              "lbmpc_halfspace_max_noalloc")
+    return out
+
+
 def homothety_lp(WA, Wb, m, alpha=None, v=None):
     lib = core.init()
     WA, Wb = fcol(WA), fcol(Wb).ravel()
