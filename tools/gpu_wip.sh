@@ -1,0 +1,3 @@
+set -e
+cd $GRAFT_REPO_ROOT
+timeout -k 10 300 python -u -m pytest tests/wip_no_alloc.py -x -v --timeout 120 --timeout-method thread -m gpu 2>&1 | tail -25
