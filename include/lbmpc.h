@@ -283,9 +283,11 @@ int lbmpc_mc_run_dev(lbmpc_ctx* ctx, const lbmpc_sampler* smp, const lbmpc_mc_cf
 /* Work counters of the last lbmpc_mc_run / lbmpc_mc_run_dev on this context (synchronises the device).  No
  * counterpart in the reference (its loops are timed with tic/toc, Case_3...:57,69); used by bench.py to state the
  * arithmetic that was actually executed.  out[0] wave-steps whose rows were scanned by the fp32 filter (64 trials
- * each), out[1] wave-steps in total, out[2] QP solves, out[3] solver rounds (up to 4 QPs each), out[4] solver loop
- * trips, out[5] full pivot scans (4 QPs each), out[6] passes over the H rows inside them (2 QPs each), out[7] reserved. */
-int lbmpc_mc_counters(lbmpc_ctx* ctx, uint64_t* out8);
+ * each), out[1] wave-steps in total, out[2] QP solves, then the 16-lane-row solver: out[3] rounds (up to 4 QPs each),
+ * out[4] loop trips, out[5] full pivot scans (4 QPs each), out[6] passes over the H rows inside them (2 QPs each);
+ * the one-QP-per-lane solver of the S-row regime: out[7] loop trips (up to 64 QPs each), out[8] scan passes over
+ * the S rows (up to 4 QPs each); out[9] QPs that went through the 16-lane-row solver; out[10..11] reserved. */
+int lbmpc_mc_counters(lbmpc_ctx* ctx, uint64_t* out12);
 
 #ifdef __cplusplus
 }

@@ -51,6 +51,7 @@ struct CtxDev {
     double ME[LBMPC_MAX_NX * LBMPC_MAX_NX], bmin;
     double cmH[LBMPC_MAX_NZ];  // max_h |H[h,k]|: certificate that no H row is violated (qp_group.hpp, scan_rows)
     int hasE;
+    int lane_solver;     // 1: try the one-QP-per-lane solver of the S-row regime first (qp_lane.hpp)
     const double* Hm;    // nH x nzp: rows of F_bar Psi^i, i = 0..Nu
     const double* Ginv;  // nz x nz : (2 blkdiag(Px,Pc))^-1
 };
@@ -69,7 +70,7 @@ struct lbmpc_ctx {
     size_t xi_bytes = 0;
     int* xi_status = nullptr;
     size_t xi_status_n = 0;
-    unsigned long long* counters = nullptr;  // 8 work counters of the last mc_run
+    unsigned long long* counters = nullptr;  // 12 work counters of the last mc_run
     int* hint = nullptr;                     // pivot candidates, 17 ints per chunk trial (16 rows + count)
     size_t hint_n = 0;
     double* st_d = nullptr;                  // trial state handed between step segments: (3 nx + 1) doubles ...
@@ -97,6 +98,7 @@ __host__ __device__ inline int ws_doubles(int) { return 4 * 48; }  // GWS_PER_WA
 }  // namespace lbmpc
 
 #include "qp_group.hpp"
+#include "qp_lane.hpp"
 
 namespace lbmpc {
 
@@ -325,13 +327,13 @@ __device__ __forceinline__ void solve_flagged(const CtxDev* __restrict__ C, cons
                                               bool need, double alpha, const double* v, const double* q,
                                               double* s0, double* c0, int& status, int& iters,
                                               int* nact_out, int* act_out /* NZMAX, sorted, or null */,
-                                              double* c_full /* nz-NX or null */, unsigned* ctr /* [0] solves [1] rounds [2] trips [3] scans [4] H passes */,
+                                              double* c_full /* nz-NX or null */, unsigned* ctr /* [1] rounds [2] trips [3] scans [4] H passes [7] QPs solved here */,
                                               int* hint_base /* [chunk trial][16] pivot candidates in HBM, or null */,
                                               int* nhint_base /* [chunk trial] */, int cl /* this lane's chunk trial */,
                                               long long* prof = nullptr) {
     const int lane = lane_id(), grp = lane >> 4;
     uint64_t mask = __builtin_amdgcn_ballot_w64(need);
-    ctr[0] += (unsigned)__builtin_popcountll(mask);
+    ctr[7] += (unsigned)__builtin_popcountll(mask);
     while (mask) {
         ctr[1] += 1;
         int src[4];
@@ -389,6 +391,50 @@ __device__ __forceinline__ void solve_flagged(const CtxDev* __restrict__ C, cons
     }
 }
 
+// Solve the QPs of the flagged lanes: the one-QP-per-lane solver of the S-row regime first (qp_lane.hpp), then the
+// 16-lane-row solver for the lanes that left it (rows of F_bar Psi^i in play).  Same outputs as solve_flagged.
+// ctr: [0] QPs, [1] rounds, [2] trips, [3] scans, [4] H passes of the row solver, [5] lane-solver trips,
+// [6] lane-solver scan passes, [7] QPs that went through the row solver.
+template <int NX>
+__device__ __forceinline__ void solve_lanes(const CtxDev* __restrict__ C, const LdsView& L, double* wws, bool need,
+                                            double alpha, const double* v, const double* q, double min_omh, double* s0,
+                                            double* c0, int& status, int& iters, int* nact_out, int* act_out,
+                                            double* c_full, unsigned* ctr, int* hint_base, int* nhint_base, int cl,
+                                            long long* prof = nullptr) {
+    ctr[0] += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(need));
+    bool fb = need;
+    if (C->lane_solver) {
+        double zf[NX];
+        int st_f = 0, it_f = 0, na_f = 0, act_f[NX];
+        lane_qp_solve<NX>(C, L, need, alpha, q, min_omh, hint_base ? hint_base + (int64_t)cl * 16 : nullptr,
+                          nhint_base ? nhint_base + cl : nullptr, zf, st_f, it_f, na_f, act_f, fb, ctr + 5);
+        if (need && !fb) {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) s0[k] = zf[k];
+#pragma unroll
+            for (int j = 0; j < LBMPC_MAX_NU; ++j) c0[j] = 0.0;
+            status = st_f > status ? st_f : status;
+            iters += it_f;
+            if (nact_out) *nact_out = na_f;
+            if (act_out) {
+                for (int a = 0; a < NZMAX; ++a) act_out[a] = -1;
+#pragma unroll
+                for (int a = 0; a < NX; ++a)
+                    if (a < na_f) {  // ascending insertion
+                        int pos = a;
+                        while (pos > 0 && act_out[pos - 1] > act_f[a]) { act_out[pos] = act_out[pos - 1]; --pos; }
+                        act_out[pos] = act_f[a];
+                    }
+            }
+            if (c_full) for (int k = NX; k < C->nz; ++k) c_full[k - NX] = 0.0;
+        }
+        fb = need && fb;
+    }
+    if (__builtin_amdgcn_ballot_w64(fb) != 0)
+        solve_flagged<NX>(C, L, wws, fb, alpha, v, q, s0, c0, status, iters, nact_out, act_out, c_full, ctr, hint_base,
+                          nhint_base, cl, prof);
+}
+
 // ---- single-step kernel (lbmpc_uqmpc_step): lane per problem -------------------------------------
 struct StepIO {
     const double *x, *alpha_prev, *v_prev, *w_new;
@@ -427,9 +473,9 @@ __global__ __launch_bounds__(256) void uqmpc_step_kernel(const CtxDev* __restric
         double* cdst = (valid && io.c) ? io.c + b * ncv : nullptr;
         if (cdst) for (int k = 0; k < ncv; ++k) cdst[k] = 0.0;
         if (valid && io.active_set) for (int a = 0; a < NZMAX; ++a) io.active_set[b * NZMAX + a] = -1;
-        unsigned ctr[5] = {0, 0, 0, 0, 0};
-        solve_flagged<NX>(C, L, ws, valid && need[0], alpha[0], v, q[0], s0, c0, status, iters,
-                          &nact, (valid && io.active_set) ? io.active_set + b * NZMAX : nullptr, cdst, ctr, nullptr, nullptr, 0);
+        unsigned ctr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        solve_lanes<NX>(C, L, ws, valid && need[0], alpha[0], v, q[0], momh[0], s0, c0, status, iters,
+                        &nact, (valid && io.active_set) ? io.active_set + b * NZMAX : nullptr, cdst, ctr, nullptr, nullptr, 0);
         if (!valid) continue;
         if (io.s0) for (int k = 0; k < NX; ++k) io.s0[b * NX + k] = s0[k];
         if (io.u)
@@ -488,7 +534,7 @@ struct McArgs {
     int64_t chunk0, chunk_n;
     const double* xi;       // pre-drawn xi_LV / xi_EV, layout xi_index()
     const int* xi_status;   // [chunk trial] LBMPC_ST_SAMPLER_CAP if a step sampler hit the attempt cap
-    unsigned long long* counters;  // 8 work counters of this launch
+    unsigned long long* counters;  // 12 work counters of this launch
     int* hint;              // [chunk trial][16] final active set of the trial's previous step (pivot candidates)
     int* nhint;             // [chunk trial] its size
     double* park;           // [slot][thread of the grid]: closed-loop state parked during a solve (mc_kernel)
@@ -613,7 +659,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
     const int nz = C->nz, nu = C->nu, K = a.steps;
     double* ws = ws_base + wave * ws_doubles(nz);
     const SamplerDev* S = &smp;
-    unsigned ctr[7] = {0, 0, 0, 0, 0, 0, 0};  // wave-uniform work counters (lbmpc_mc_counters)
+    unsigned ctr[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // wave-uniform work counters (lbmpc_mc_counters)
 #ifdef LBMPC_PROFILE
     long long prof[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     PROF_T(pk0);
@@ -771,11 +817,11 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
                     pk[(slot++) * ps] = __longlong_as_double(cl[tt]);
                     pk[(slot++) * ps] = __longlong_as_double((long long)tid[tt]);
                 }
-                double a_c[T], v_c[T][NX], q_c[T][NX];
+                double a_c[T], v_c[T][NX], q_c[T][NX], mo_c[T];
                 int cl_c[T];
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
-                    a_c[t] = alpha[t]; cl_c[t] = (int)cl[t];
+                    a_c[t] = alpha[t]; cl_c[t] = (int)cl[t]; mo_c[t] = momh[t];
 #pragma unroll
                     for (int i = 0; i < NX; ++i) { v_c[t][i] = v[t][i]; q_c[t][i] = q[t][i]; }
                 }
@@ -799,8 +845,8 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
 #endif
                     if (__builtin_amdgcn_ballot_w64(nd) != 0) {
                         int nact_t = 0;
-                        solve_flagged<NX>(C, L, ws, nd, a_c[t], v_c[t], q_c[t], s0[t], c0[t], status[t], iters[t],
-                                          &nact_t, nullptr, nullptr, ctr + 2, a.hint, a.nhint, cl_c[t], PROF_PTR);
+                        solve_lanes<NX>(C, L, ws, nd, a_c[t], v_c[t], q_c[t], mo_c[t], s0[t], c0[t], status[t], iters[t],
+                                        &nact_t, nullptr, nullptr, ctr + 2, a.hint, a.nhint, cl_c[t], PROF_PTR);
                         if (nd) hashint[t] = nact_t > 0;
                     }
                 }
@@ -898,7 +944,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
         }
     }
     if (lane == 0 && a.counters)
-        for (int i = 0; i < 7; ++i) atomicAdd(a.counters + i, (unsigned long long)ctr[i]);
+        for (int i = 0; i < 10; ++i) atomicAdd(a.counters + i, (unsigned long long)ctr[i]);
 #ifdef LBMPC_PROFILE
     PROF_T(pk1);
     prof[6] = pk1 - pk0;
@@ -1230,6 +1276,10 @@ extern "C" int lbmpc_uqmpc_create(const lbmpc_params* p, lbmpc_ctx** out) {
         }
     }
     inscribed_ellipsoid(nx, nS, p->S_A, p->S_b, &h);
+    {
+        const char* env_ls = getenv("LBMPC_LANE_SOLVER");   // 0: 16-lane-row solver only (testing)
+        h.lane_solver = !(env_ls && atoi(env_ls) == 0);
+    }
     // H rows: F_bar Psi^i, i = 0..Nu  (UQRobustMPC.m:153-155)
     std::vector<double> Hm((size_t)nH * h.nzp, 0.0), M((size_t)nc * nz), M2((size_t)nc * nz);
     for (int r = 0; r < nc; ++r) for (int k = 0; k < nz; ++k) M[r * nz + k] = CMX(p->F_bar, nc, r, k);
@@ -1397,8 +1447,8 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
             c->xi_status_n = (size_t)chunk;
         }
     }
-    if (!c->counters) LB_HIP(hipMalloc((void**)&c->counters, 8 * sizeof(unsigned long long)));
-    LB_HIP(hipMemsetAsync(c->counters, 0, 8 * sizeof(unsigned long long), st));
+    if (!c->counters) LB_HIP(hipMalloc((void**)&c->counters, 12 * sizeof(unsigned long long)));
+    LB_HIP(hipMemsetAsync(c->counters, 0, 12 * sizeof(unsigned long long), st));
     if ((size_t)chunk > c->hint_n) {
         if (c->hint) LB_HIP(hipFree(c->hint));
         c->hint = nullptr; c->hint_n = 0;
@@ -1497,15 +1547,15 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
     return 0;
 }
 
-extern "C" int lbmpc_mc_counters(lbmpc_ctx* c, uint64_t* out8) {
+extern "C" int lbmpc_mc_counters(lbmpc_ctx* c, uint64_t* out12) {
     if (int rc = check_any_device()) return rc;
-    if (!c || !out8) { set_error("lbmpc_mc_counters: null argument"); return LBMPC_ERR_ARG; }
-    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    if (!c || !out12) { set_error("lbmpc_mc_counters: null argument"); return LBMPC_ERR_ARG; }
+    for (int i = 0; i < 12; ++i) out12[i] = 0;
     if (!c->counters) return 0;
     DeviceGuard guard(c->device);
     if (guard.rc()) return guard.rc();
     LB_HIP(hipDeviceSynchronize());
-    LB_HIP(hipMemcpy(out8, c->counters, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    LB_HIP(hipMemcpy(out12, c->counters, 12 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return 0;
 }
 

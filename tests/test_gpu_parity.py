@@ -328,7 +328,10 @@ def test_mc_generated_systems_vs_oracle(core, system, x0, steps):
     assert o["qp_iters"].min() > 0
     cnt = ctx.mc_counters()
     assert cnt["wave_steps"] % steps == 0 and cnt["wave_steps"] >= 4 * steps   # 200 trials in waves of 4 .. 64
-    assert cnt["qp_solves"] > 0 and cnt["pivot_scans"] >= cnt["solver_rounds"] > 0
+    assert cnt["qp_solves"] > 0 and cnt["pivot_scans"] >= cnt["solver_rounds"] >= 0
+    # every QP went through one of the two solvers (the one-QP-per-lane solver of the S-row regime first)
+    assert cnt["lane_scans"] + cnt["pivot_scans"] > 0 and cnt["row_solver_qps"] <= cnt["qp_solves"]
+    assert (cnt["row_solver_qps"] > 0) == (cnt["solver_rounds"] > 0)
     assert 0 < cnt["filter_wave_steps"] < cnt["wave_steps"]   # transient scanned, steady state skipped
     ctx.close(); octx.close()
 

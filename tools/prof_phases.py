@@ -6,7 +6,7 @@ from lbmpc import core, params, _abi
 
 P = params.load("4x4")
 ctx = core.Context(P)
-smp = params.sampler(P)
+smp = params.sampler(P, oriented=True)
 trials = int(os.environ.get("TRIALS", 131072)); K = int(os.environ.get("K", 1000))
 lib = _abi.load()
 buf = (ctypes.c_ulonglong * 24)()
