@@ -142,24 +142,22 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
     }
 }
 
-__device__ __forceinline__ double u01(uint32_t lo, uint32_t hi) {
-    uint64_t x = ((uint64_t)hi << 32) | lo;
-    return (double)(x >> 11) * 0x1.0p-53;
-}
+// One 32-bit word -> uniform in (0, 1): (w + 1/2) 2^-32, exact in fp64 (granularity 2^-32 of the box width; the
+// end points are never returned).  One Philox block therefore serves a whole proposal point (nx <= 4) or input
+// draw (nu <= 4): a trial-step costs 3 blocks (xi_LV, u_LV, xi_EV) instead of the 5 of 53-bit uniforms.
+__device__ __forceinline__ double u01(uint32_t w) { return ((double)w + 0.5) * 0x1.0p-32; }
 
 enum { P_I0_U = 0, P_I0_EV = 1, P_I0_LV = 2, P_ST_LV = 3, P_ST_U = 4, P_ST_EV = 5 };
 
+// N <= 4 uniforms of stream (seed, trial): draw (index, purpose, attempt) is ONE Philox4x32-10 block
 template <int N>
 __device__ __forceinline__ void draw_uniforms(uint64_t seed, uint64_t trial, uint32_t index,
                                               uint32_t purpose, uint32_t attempt, double* out) {
+    static_assert(N <= 4, "one Philox block per draw");
+    uint32_t c[4] = {(uint32_t)trial, (uint32_t)(trial >> 32), index, (purpose << 28) | (attempt << 4)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
 #pragma unroll
-    for (int blk = 0; 2 * blk < N; ++blk) {
-        uint32_t c[4] = {(uint32_t)trial, (uint32_t)(trial >> 32), index,
-                         (purpose << 28) | (attempt << 4) | (uint32_t)blk};
-        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-        out[2 * blk] = u01(c[0], c[1]);
-        if (2 * blk + 1 < N) out[2 * blk + 1] = u01(c[2], c[3]);
-    }
+    for (int k = 0; k < N; ++k) out[k] = u01(c[k]);
 }
 
 // Device-resident description of the two disturbance polytopes + input range (lbmpc_sampler),
@@ -207,7 +205,7 @@ __device__ __forceinline__ bool sample_polytope(const double* __restrict__ XA, c
     bool done = false;
     for (int a = 0; a < max_attempts; ++a) {
         if (!done) {
-            double u[NX + (NX & 1)];
+            double u[NX];
             double xt[NX];
             draw_uniforms<NX>(seed, trial, index, purpose, (uint32_t)a, u);
             proposal_point<NX>(lo, hi, U, u, xt);
@@ -227,28 +225,22 @@ __device__ __forceinline__ bool sample_polytope(const double* __restrict__ XA, c
     return !done;
 }
 
-// u_LV ~ U[min_u, max_u]^nu; returns B u (nx).  nu <= 2 uses one Philox block.
+// u_LV ~ U[min_u, max_u]^nu; returns B u (nx).  One Philox block (nu <= 4).
 template <int NX>
 __device__ __forceinline__ void sample_Bu_lv(const SamplerDev* __restrict__ s, uint64_t seed, uint64_t trial,
                                              uint32_t index, uint32_t purpose, double* Bu) {
-    double acc[NX];
+    double acc[NX], r[LBMPC_MAX_NU];
 #pragma unroll
     for (int i = 0; i < NX; ++i) acc[i] = 0.0;
     const int nu = s->nu;
-    for (int blk = 0; 2 * blk < nu; ++blk) {
-        uint32_t c[4] = {(uint32_t)trial, (uint32_t)(trial >> 32), index, (purpose << 28) | (uint32_t)blk};
-        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-        double r0 = u01(c[0], c[1]), r1 = u01(c[2], c[3]);
-        int j0 = 2 * blk, j1 = 2 * blk + 1;
-        double u0 = (s->max_u[j0] - s->min_u[j0]) * r0 + s->min_u[j0];
+    draw_uniforms<LBMPC_MAX_NU>(seed, trial, index, purpose, 0u, r);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) acc[i] = fma(s->B[i * nu + j0], u0, acc[i]);
-        if (j1 < nu) {
-            double u1 = (s->max_u[j1] - s->min_u[j1]) * r1 + s->min_u[j1];
+    for (int j = 0; j < LBMPC_MAX_NU; ++j)
+        if (j < nu) {
+            const double uj = (s->max_u[j] - s->min_u[j]) * r[j] + s->min_u[j];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) acc[i] = fma(s->B[i * nu + j1], u1, acc[i]);
+            for (int i = 0; i < NX; ++i) acc[i] = fma(s->B[i * nu + j], uj, acc[i]);
         }
-    }
 #pragma unroll
     for (int i = 0; i < NX; ++i) Bu[i] = acc[i];
 }
@@ -273,6 +265,7 @@ struct BoxW {
     double WA[LBMPC_MAX_NW * LBMPC_MAX_NX];    // canonical rows, row-major (caller's values)
     double Wb[LBMPC_MAX_NW];
     double ic[LBMPC_MAX_NW];                   // 1 / |axis coefficient|
+    int exact;                                 // every off-axis coefficient is an exact zero: row r = WA[r][r/2] e_{r/2}
 };
 int pack_box(const double* WA, const double* Wb, int nW, int nx, BoxW* out);  // host
 

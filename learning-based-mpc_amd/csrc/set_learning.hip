@@ -480,9 +480,13 @@ int pack_box(const double* WA, const double* Wb, int nW, int nx, BoxW* o) {
         o->perm[r] = j;
         o->ic[r] = 1.0 / fabs(a);
     }
+    o->exact = 1;
     for (int r = 0; r < nW; ++r) {
         if (o->perm[r] < 0) { set_error("W is unbounded along an axis"); return LBMPC_ERR_UNSUPPORTED; }
-        for (int k = 0; k < nx; ++k) o->WA[r * nx + k] = WA[o->perm[r] + (size_t)nW * k];
+        for (int k = 0; k < nx; ++k) {
+            o->WA[r * nx + k] = WA[o->perm[r] + (size_t)nW * k];
+            if (k != r / 2 && o->WA[r * nx + k] != 0.0) o->exact = 0;
+        }
         o->Wb[r] = Wb[o->perm[r]];
     }
     return 0;

@@ -5,7 +5,7 @@
 // loops of Cases_general/Case_{3,4,5}.
 //
 // Execution model (DESIGN.md "Kernel 3"):
-//   * mc_sample_kernel (pre-pass): the step disturbances xi_LV + B u_LV and xi_EV of a trial chunk, four adjacent
+//   * mc_sample_kernel (pre-pass): the step disturbances w = (xi_EV - xi_LV) - B u_LV of a trial chunk, four adjacent
 //     trials per thread, stored step-major so that both this kernel's stores and the step loop's loads are whole lines;
 //   * mc_kernel / uqmpc_step_kernel, lane per trial (T trials per lane): online set update (closed-form homothety LP),
 //     h_k in closed form, then the first pass at the unconstrained minimiser z = 0 as a conservative filter -- inscribed
@@ -104,14 +104,24 @@ namespace lbmpc {
 
 // ---- lane-per-trial pieces ----------------------------------------------------------------------
 
+// W_A[r,:] . x for canonical row r.  For an exact box (every off-axis coefficient an exact zero: all reference
+// configurations) the fma chain of the dense form collapses to its one non-zero term, fma(a, x_k, 0.0), bit for bit
+// (the other terms add exact zeros; a zero product gives +0.0 in both forms).
+template <int NX>
+__device__ __forceinline__ double box_row_dot(const CtxDev* __restrict__ C, int r, const double* x) {
+    if (C->box.exact) return fma(C->box.WA[r * NX + (r >> 1)], x[r >> 1], 0.0);
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) t = fma(C->box.WA[r * NX + k], x[k], t);
+    return t;
+}
+
 // b_hat = alpha W_b + (1-alpha) W_A v (canonical row order)
 template <int NX>
 __device__ __forceinline__ void w_hat_b(const CtxDev* __restrict__ C, double alpha, const double* v, double* bh) {
 #pragma unroll
     for (int r = 0; r < 2 * NX; ++r) {
-        double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < NX; ++k) t = fma(C->box.WA[r * NX + k], v[k], t);
+        const double t = box_row_dot<NX>(C, r, v);
         bh[r] = alpha * C->box.Wb[r] + (1.0 - alpha) * t;
     }
 }
@@ -127,9 +137,7 @@ __device__ __forceinline__ int uq_update(const CtxDev* __restrict__ C, double& a
     w_hat_b<NX>(C, alpha, v, bh);
 #pragma unroll
     for (int r = 0; r < 2 * NX; ++r) {
-        double hw = 0.0;
-#pragma unroll
-        for (int k = 0; k < NX; ++k) hw = fma(C->box.WA[r * NX + k], w[k], hw);
+        const double hw = box_row_dot<NX>(C, r, w);
         mm[r] = bh[r];
         if (hw > bh[r]) { mm[r] = hw; outside = true; }
     }
@@ -532,7 +540,7 @@ struct McArgs {
     int* st_i;     // [5][chunk trial]: status, infeasible, iters, hashint, kpos
     // this launch covers local trials [chunk0, chunk0 + chunk_n); xi holds their pre-drawn step disturbances
     int64_t chunk0, chunk_n;
-    const double* xi;       // pre-drawn xi_LV / xi_EV, layout xi_index()
+    const double* xi;       // pre-drawn step disturbances, layout xi_index()
     const int* xi_status;   // [chunk trial] LBMPC_ST_SAMPLER_CAP if a step sampler hit the attempt cap
     unsigned long long* counters;  // 12 work counters of this launch
     int* hint;              // [chunk trial][16] final active set of the trial's previous step (pivot candidates)
@@ -541,101 +549,52 @@ struct McArgs {
     lbmpc_mc_out out;
 };
 
-// Layout of the pre-drawn disturbances: [kind][step][chunk trial][nx] with chunk trials padded to a multiple of 4;
-// kind 0 holds xi_LV + B u_LV (the sum the plant update subtracts), kind 1 holds xi_EV.  A closed-loop step reads
-// one contiguous 64*nx*8-byte window per kind and wave; the pre-pass writes it in full lines (4 trials per thread).
+// Layout of the pre-drawn step disturbances w = (xi_EV - xi_LV) - B u_LV: [step][chunk trial][nx] with chunk trials
+// padded to a multiple of 4.  A closed-loop step reads one contiguous 64*nx*8-byte window per wave; the pre-pass
+// writes it in full lines (4 trials per thread).
 template <int NX>
-__host__ __device__ inline int64_t xi_index(int kind, int64_t cl, int k, int K, int64_t chunk_n) {
+__host__ __device__ inline int64_t xi_index(int64_t cl, int k, int64_t chunk_n) {
     const int64_t np = (chunk_n + 3) & ~(int64_t)3;
-    return (((int64_t)kind * K + k) * np + cl) * NX;
+    return ((int64_t)k * np + cl) * NX;
 }
 __host__ inline size_t xi_bytes_for(int nx, int K, int64_t chunk_n) {
-    return (size_t)2 * (size_t)K * (size_t)((chunk_n + 3) & ~(int64_t)3) * nx * 8;
+    return (size_t)K * (size_t)((chunk_n + 3) & ~(int64_t)3) * nx * 8;
 }
 
 // ---- step-disturbance pre-pass ------------------------------------------------------------------------
-// xi_LV / xi_EV of every (trial, step) by rejection sampling (ModelingCar.m:36-43 via :47-91).  The draws depend on
-// (seed, trial, step, attempt) only, not on the closed-loop state, so they are produced ahead of the closed loop:
-// here every lane walks its own (step, attempt) sequence and no lane waits for another lane's rejections (inside
-// the lock-step closed loop a wave pays the maximum attempt count of its 64 lanes at every step).
-// grid.y = 0: xi_LV (+ B u_LV, ModelingCar.m:42-43), 1: xi_EV; grid.z splits the steps into equal segments (more waves
-// in flight).  Every thread serves FOUR adjacent trials, step by step, so that the four accepted draws of a step leave
-// as one contiguous 4*nx*8-byte run of the step-major layout (a full 128-byte line at nx = 4): single 32-byte stores
-// cost as much as the sampling itself.  Same streams and arithmetic as sample_polytope / sample_Bu_lv.
-template <int NX, int KIND>
-__device__ __forceinline__ void mc_sample_body(const SamplerDev& smp, int64_t chunk_n, int64_t trial_first, int K,
-                                               uint64_t seed, int max_attempts, double* __restrict__ xi,
-                                               int* __restrict__ xi_status) {
-    constexpr int kind = KIND;  // compile-time: the fields of the by-value descriptor are read in place (kernarg)
-    const int64_t g4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // trials 4 g4 .. 4 g4 + 3 of the chunk
-    const int64_t ngroups = (chunk_n + 3) >> 2;
-    const bool valid = g4 < ngroups;
-    const int64_t cl0 = valid ? 4 * g4 : 0;
-    const double* XA = KIND ? smp.EV_A : smp.LV_A;
-    const double* Xb = KIND ? smp.EV_b : smp.LV_b;
-    const double* lo = KIND ? smp.EV_lo : smp.LV_lo;
-    const double* hi = KIND ? smp.EV_hi : smp.LV_hi;
-    const int nr = KIND ? smp.nEV : smp.nLV;
-    const double* PUm = KIND ? smp.EV_U : smp.LV_U;
-    const bool hasU = KIND ? smp.EV_hasU != 0 : smp.LV_hasU != 0;
-    const uint32_t purpose = KIND ? P_ST_EV : P_ST_LV;
-    const int seg = (K + (int)gridDim.z - 1) / (int)gridDim.z;
-    const int kbeg = (int)blockIdx.z * seg < K ? (int)blockIdx.z * seg : K;
-    const int kend = kbeg + seg < K ? kbeg + seg : K;
-    double buf[4][NX];
-    int k = valid ? kbeg : kend, j = 0, att = 0, st = 0;  // task = (step k, trial cl0 + j)
-    while (__builtin_amdgcn_ballot_w64(k < kend) != 0) {
-        if (k < kend) {
-            const int64_t clj = cl0 + j < chunk_n ? cl0 + j : chunk_n - 1;  // padding trials repeat the last one
-            const uint64_t tid = (uint64_t)(trial_first + clj);
-            double u[NX + (NX & 1)], xt[NX];
-            draw_uniforms<NX>(seed, tid, (uint32_t)k, purpose, (uint32_t)att, u);
-            if (hasU) proposal_point<NX>(lo, hi, PUm, u, xt); else proposal_point<NX>(lo, hi, nullptr, u, xt);
-            bool ok = true;
-            for (int r = 0; r < nr; ++r) {
-                double acc = 0.0;
-#pragma unroll
-                for (int i = 0; i < NX; ++i) acc = fma(XA[r * NX + i], xt[i], acc);
-                ok = ok && (acc <= Xb[r]);
-            }
-            const bool last = att + 1 >= max_attempts;
-            if (ok || last) {
-                if (kind == 0) {  // the plant update subtracts (xi_LV + B u_LV): form that sum here
-                    double Bul[NX];
-                    sample_Bu_lv<NX>(&smp, seed, tid, (uint32_t)k, P_ST_U, Bul);
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) xt[i] = xt[i] + Bul[i];
-                }
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) buf[jj][i] = j == jj ? xt[i] : buf[jj][i];
-                if (!ok && cl0 + j < chunk_n) atomicMax(&xi_status[cl0 + j], (int)LBMPC_ST_SAMPLER_CAP);
-                att = 0;
-                if (j == 3) {
-                    double* dst = xi + xi_index<NX>(kind, cl0, k, K, chunk_n);
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                        for (int i = 0; i < NX; ++i) dst[jj * NX + i] = buf[jj][i];
-                    j = 0; ++k;
-                } else {
-                    ++j;
-                }
-            } else {
-                ++att;
-            }
-        }
-    }
-    (void)st;
-}
-
+// w = (xi_EV - xi_LV) - B u_LV of every (trial, step): xi_* by rejection sampling (ModelingCar.m:36-43 via :47-91), in
+// the form the information set uses (InitialSetComputation.m:51-52).  The draws depend on (seed, trial, step, attempt)
+// only, not on the closed-loop state, so they are produced ahead of the closed loop, one trial per lane, step by step:
+// the wave's stores of a step are one contiguous 64*nx*8-byte run of the step-major layout.  A wave repeats a draw
+// until its last lane has accepted (sample_polytope): free with the tight proposal boxes (lbmpc_sampler.EV_U / LV_U:
+// acceptance ~1), a few extra attempts per draw with loose axis-aligned ones.  grid.y splits the steps into equal
+// segments (more waves in flight).  3 Philox blocks per trial-step.
 template <int NX>
 __global__ __launch_bounds__(256) void mc_sample_kernel(SamplerDev smp, int64_t chunk_n, int64_t trial_first, int K,
                                                         uint64_t seed, int max_attempts, double* __restrict__ xi,
                                                         int* __restrict__ xi_status) {
-    if (blockIdx.y == 0) mc_sample_body<NX, 0>(smp, chunk_n, trial_first, K, seed, max_attempts, xi, xi_status);
-    else mc_sample_body<NX, 1>(smp, chunk_n, trial_first, K, seed, max_attempts, xi, xi_status);
+    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = l < chunk_n;
+    const int64_t cl = valid ? l : chunk_n - 1;   // idle lanes of the last wave repeat the last trial (no stores)
+    const uint64_t tid = (uint64_t)(trial_first + cl);
+    const int seg = (K + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int kbeg = (int)blockIdx.y * seg < K ? (int)blockIdx.y * seg : K;
+    const int kend = kbeg + seg < K ? kbeg + seg : K;
+    bool cap = false;
+    for (int k = kbeg; k < kend; ++k) {
+        double lv[NX], ev[NX], Bul[NX];
+        if (smp.LV_hasU) cap |= sample_polytope<NX>(smp.LV_A, smp.LV_b, smp.nLV, smp.LV_lo, smp.LV_hi, smp.LV_U, seed, tid, (uint32_t)k, P_ST_LV, max_attempts, lv);
+        else cap |= sample_polytope<NX>(smp.LV_A, smp.LV_b, smp.nLV, smp.LV_lo, smp.LV_hi, nullptr, seed, tid, (uint32_t)k, P_ST_LV, max_attempts, lv);
+        sample_Bu_lv<NX>(&smp, seed, tid, (uint32_t)k, P_ST_U, Bul);
+        if (smp.EV_hasU) cap |= sample_polytope<NX>(smp.EV_A, smp.EV_b, smp.nEV, smp.EV_lo, smp.EV_hi, smp.EV_U, seed, tid, (uint32_t)k, P_ST_EV, max_attempts, ev);
+        else cap |= sample_polytope<NX>(smp.EV_A, smp.EV_b, smp.nEV, smp.EV_lo, smp.EV_hi, nullptr, seed, tid, (uint32_t)k, P_ST_EV, max_attempts, ev);
+        if (valid) {
+            double* dst = xi + xi_index<NX>(cl, k, chunk_n);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) dst[i] = (ev[i] - lv[i]) - Bul[i];
+        }
+    }
+    if (valid && cap) atomicMax(&xi_status[cl], (int)LBMPC_ST_SAMPLER_CAP);
 }
 
 #ifdef LBMPC_PROFILE
@@ -746,13 +705,12 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
                         stale[t] = true; live[t] = true;
                     }
             }
-            double q[T][NX], xi_lv[T][NX], xi_ev[T][NX], momh[T];
+            double q[T][NX], wk[T][NX], momh[T];   // wk: this step's disturbance (xi_EV - xi_LV) - B u_LV from the pre-pass
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                const double* xl = a.xi + xi_index<NX>(0, cl[t], k, K, a.chunk_n);
-                const double* xe = a.xi + xi_index<NX>(1, cl[t], k, K, a.chunk_n);
+                const double* xw = a.xi + xi_index<NX>(cl[t], k, a.chunk_n);
 #pragma unroll
-                for (int i = 0; i < NX; ++i) { xi_lv[t][i] = xl[i]; xi_ev[t][i] = xe[i]; }
+                for (int i = 0; i < NX; ++i) wk[t][i] = xw[i];
             }
             int aomh[T];
             bool need[T];
@@ -810,7 +768,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
 #pragma unroll
                     for (int i = 0; i < NX; ++i) {
                         pk[(slot++) * ps] = x[tt][i]; pk[(slot++) * ps] = v[tt][i];
-                        pk[(slot++) * ps] = xi_lv[tt][i]; pk[(slot++) * ps] = xi_ev[tt][i];
+                        pk[(slot++) * ps] = wk[tt][i];
                     }
                     pk[(slot++) * ps] = alpha[tt];
                     pk[(slot++) * ps] = __longlong_as_double(tl[tt]);
@@ -857,7 +815,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
 #pragma unroll
                     for (int i = 0; i < NX; ++i) {
                         x[tt][i] = pk[(slot++) * ps]; v[tt][i] = pk[(slot++) * ps];
-                        xi_lv[tt][i] = pk[(slot++) * ps]; xi_ev[tt][i] = pk[(slot++) * ps];
+                        wk[tt][i] = pk[(slot++) * ps];
                     }
                     alpha[tt] = pk[(slot++) * ps];
                     tl[tt] = __double_as_longlong(pk[(slot++) * ps]);
@@ -896,7 +854,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
 #pragma unroll
                     for (int j = 0; j < LBMPC_MAX_NU; ++j) if (j < nu) bcc = fma(C->B[i * nu + j], u[j], bcc);
                     Ax[i] = acc; Bu[i] = bcc;
-                    xn[i] = ((Ax[i] + Bu[i]) + xi_ev[t][i]) - xi_lv[t][i];  // xi_lv holds xi_LV + B u_LV
+                    xn[i] = (Ax[i] + Bu[i]) + wk[t][i];   // relative dynamics x+ = (A x + B u) + w
                 }
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
@@ -996,12 +954,11 @@ __global__ __launch_bounds__(256) void mc_steady_kernel(const CtxDev* __restrict
     for (int i = 0; i < NX; ++i) bTv[i] = 0.0;
     for (int k = a.kseg0; k < a.kseg1; ++k) {
         if (__builtin_amdgcn_ballot_w64(active) == 0) break;
-        double xi_lv[NX], xi_ev[NX];
+        double wk[NX];
         {
-            const double* xl = a.xi + xi_index<NX>(0, c, k, K, cn);
-            const double* xe = a.xi + xi_index<NX>(1, c, k, K, cn);
+            const double* xw = a.xi + xi_index<NX>(c, k, cn);
 #pragma unroll
-            for (int i = 0; i < NX; ++i) { xi_lv[i] = xl[i]; xi_ev[i] = xe[i]; }
+            for (int i = 0; i < NX; ++i) wk[i] = xw[i];
         }
         // online set update on a copy: committed only if the trial does not stop at this step
         double an[1] = {alpha}, vn[NX], bh[2 * NX], q[1][NX];
@@ -1063,7 +1020,7 @@ __global__ __launch_bounds__(256) void mc_steady_kernel(const CtxDev* __restrict
 #pragma unroll
                 for (int j = 0; j < LBMPC_MAX_NU; ++j) if (j < nu) bcc = fma(C->B[i * nu + j], u[j], bcc);
                 Ax[i] = acc; Bu[i] = bcc;
-                xn[i] = ((Ax[i] + Bu[i]) + xi_ev[i]) - xi_lv[i];
+                xn[i] = (Ax[i] + Bu[i]) + wk[i];
             }
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
@@ -1414,10 +1371,11 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
     const int waves = pick_waves(c, 8);
     if (!waves) { set_error("constants (%zu B) do not fit in LDS", c->lds_const_bytes); return LBMPC_ERR_DIM; }
     const size_t lds = c->lds_const_bytes + (size_t)waves * ws_doubles(c->h.nz) * 8;
-    // trials per wave: 64 once that still gives every SIMD two waves, else fewer lanes per wave (down to one solver
-    // round of 4 QPs per step) so that small batches spread over the chip
+    // trials per wave: 64 once that still gives every SIMD a wave of its own (1024 SIMDs, with some slack), else fewer
+    // lanes per wave so that small batches spread over the chip (measured: C3 10000 x 20 is fastest at 8, C1 65536 x 50
+    // at 32; both solvers cost per wave-trip, whatever the number of live lanes)
     int tpw = 64;
-    while (tpw > 4 && (cfg->trials + tpw - 1) / tpw < 2048) tpw >>= 1;
+    while (tpw > 4 && (cfg->trials + tpw - 1) / tpw < 1088) tpw >>= 1;
     if (const char* env_w = getenv("LBMPC_MC_TPW")) { const int v = atoi(env_w); if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) tpw = v; }
     a.tpw = tpw;
     const int per_block = waves * tpw * (wide ? 2 : 1);
@@ -1481,11 +1439,11 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
         if (cfg->steps > 0) {
             LB_HIP(hipMemsetAsync(c->xi_status, 0, (size_t)cn * sizeof(int), st));
             // enough segments to put about 8 waves on every SIMD
-            const int64_t sblocks = ((cn + 3) / 4 + 255) / 256;
-            int segs = (int)((8192 + sblocks * 8 - 1) / (sblocks * 8));
+            const int64_t sblocks = (cn + 255) / 256;
+            int segs = (int)((8192 + sblocks * 4 - 1) / (sblocks * 4));
             segs = segs < 1 ? 1 : (segs > 64 ? 64 : segs);
             if (segs > cfg->steps) segs = cfg->steps;
-            dim3 sg((unsigned)sblocks, 2, (unsigned)segs), sb(256);
+            dim3 sg((unsigned)sblocks, (unsigned)segs), sb(256);
             switch (c->h.nx) {
                 case 1: hipLaunchKernelGGL((mc_sample_kernel<1>), sg, sb, 0, st, sd, cn, cfg->trial0 + c0, cfg->steps, cfg->seed, cfg->sampler_max_attempts, c->xi, c->xi_status); break;
                 case 2: hipLaunchKernelGGL((mc_sample_kernel<2>), sg, sb, 0, st, sd, cn, cfg->trial0 + c0, cfg->steps, cfg->seed, cfg->sampler_max_attempts, c->xi, c->xi_status); break;
@@ -1499,7 +1457,7 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
         if (blocks > resident * 4) blocks = resident * 4;
         dim3 grid((unsigned)blocks), blk(waves * 64);
         {
-            const size_t need = (size_t)blocks * waves * 64 * 2 * (4 * LBMPC_MAX_NX + 4) * 8;  // T <= 2
+            const size_t need = (size_t)blocks * waves * 64 * 2 * (3 * LBMPC_MAX_NX + 4) * 8;  // T <= 2
             if (need > c->park_bytes) {
                 if (c->park) LB_HIP(hipFree(c->park));
                 c->park = nullptr; c->park_bytes = 0;
@@ -1530,12 +1488,18 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
             a.kseg0 = ksplit; a.kseg1 = cfg->steps; a.resume = 1;
             if (lean) {
                 dim3 g2((unsigned)((cn + 255) / 256)), b2(256);
+#define LAUNCH_STEADY(KERN)                                                                     \
+    do {                                                                                        \
+        if (int rc = allow_lds(KERN, lds_steady)) return rc;                                    \
+        hipLaunchKernelGGL((KERN), g2, b2, lds_steady, st, c->d, a);                            \
+    } while (0)
                 switch (c->h.nx) {
-                    case 1: if (int rc = allow_lds(mc_steady_kernel<1>, lds_steady)) return rc; hipLaunchKernelGGL((mc_steady_kernel<1>), g2, b2, lds_steady, st, c->d, a); break;
-                    case 2: if (int rc = allow_lds(mc_steady_kernel<2>, lds_steady)) return rc; hipLaunchKernelGGL((mc_steady_kernel<2>), g2, b2, lds_steady, st, c->d, a); break;
-                    case 3: if (int rc = allow_lds(mc_steady_kernel<3>, lds_steady)) return rc; hipLaunchKernelGGL((mc_steady_kernel<3>), g2, b2, lds_steady, st, c->d, a); break;
-                    default: if (int rc = allow_lds(mc_steady_kernel<4>, lds_steady)) return rc; hipLaunchKernelGGL((mc_steady_kernel<4>), g2, b2, lds_steady, st, c->d, a); break;
+                    case 1: LAUNCH_STEADY(mc_steady_kernel<1>); break;
+                    case 2: LAUNCH_STEADY(mc_steady_kernel<2>); break;
+                    case 3: LAUNCH_STEADY(mc_steady_kernel<3>); break;
+                    default: LAUNCH_STEADY(mc_steady_kernel<4>); break;
                 }
+#undef LAUNCH_STEADY
                 LB_HIP(hipGetLastError());
             }
             LAUNCH_MC_ALL();   // trials whose saved step is before the horizon's end (all of them without the lean kernel)

@@ -51,23 +51,17 @@ static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
     }
 }
 
-static double u01(uint32_t lo, uint32_t hi) {
-    uint64_t x = ((uint64_t)hi << 32) | lo;
-    return (double)(x >> 11) * 0x1.0p-53;
-}
+/* one 32-bit word -> uniform in (0, 1): (w + 1/2) 2^-32 (exact in fp64) */
+static double u01(uint32_t w) { return ((double)w + 0.5) * 0x1.0p-32; }
 
 enum { P_I0_U = 0, P_I0_EV = 1, P_I0_LV = 2, P_ST_LV = 3, P_ST_U = 4, P_ST_EV = 5 };
 
-/* `n` uniforms of stream (seed, trial), draw (index, purpose, attempt) */
+/* `n` <= 4 uniforms of stream (seed, trial): draw (index, purpose, attempt) is ONE Philox block */
 static void draw_uniforms(uint64_t seed, uint64_t trial, uint32_t index, uint32_t purpose,
                           uint32_t attempt, int n, double* out) {
-    for (int blk = 0; 2 * blk < n; ++blk) {
-        uint32_t c[4] = {(uint32_t)trial, (uint32_t)(trial >> 32), index,
-                         (purpose << 28) | (attempt << 4) | (uint32_t)blk};
-        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-        out[2 * blk] = u01(c[0], c[1]);
-        if (2 * blk + 1 < n) out[2 * blk + 1] = u01(c[2], c[3]);
-    }
+    uint32_t c[4] = {(uint32_t)trial, (uint32_t)(trial >> 32), index, (purpose << 28) | (attempt << 4)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    for (int k = 0; k < n && k < 4; ++k) out[k] = u01(c[k]);
 }
 
 /* Rejection sampling from the bounding box of the vertices against A x <= b:
@@ -876,7 +870,9 @@ int orc_mc_run(orc_ctx* c, const lbmpc_sampler* smp, const lbmpc_mc_cfg* cfg, lb
             mat_vec(c->A, nx, nx, x, Ax);
             mat_vec(c->B, nx, nu, u, Bu);
             mat_vec(c->B, nx, nu, u_lv, Bul);
-            for (int i = 0; i < nx; ++i) xn[i] = ((Ax[i] + Bu[i]) + xi_ev[i]) - (xi_lv[i] + Bul[i]);
+            /* the step disturbance in the form the information set uses (InitialSetComputation.m:51-52):
+             * w = (xi_EV - xi_LV) - B u_LV;  relative dynamics x+ = (A x + B u) + w */
+            for (int i = 0; i < nx; ++i) { double wd = (xi_ev[i] - xi_lv[i]) - Bul[i]; xn[i] = (Ax[i] + Bu[i]) + wd; }
             memcpy(xprev, x, sizeof(double) * nx);
             memcpy(uprev, u, sizeof(double) * nu);
             memcpy(x, xn, sizeof(double) * nx);

@@ -23,6 +23,8 @@ for name, P, x0, trials, steps, card in (
             dev.mc_run(ctx, smp, bufs, **kw)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 5
+        cnt = ctx.mc_counters()
+        print({k: cnt[k] for k in ("qp_solves", "solver_rounds", "pivot_scans", "h_passes", "lane_trips", "lane_scans", "row_solver_qps")})
         print(f"{name}: {trials} trials x {steps} steps, card(I0)={card}, oriented={oriented}: {dt*1e3:.2f} ms/launch, "
               f"{trials*steps/dt:.3e} steps/s, iters/trial {bufs.qp_iters.float().mean().item():.1f}, "
               f"infeasible {int(bufs.infeasible.sum().item())}, max status {int(bufs.status.max().item())}")
