@@ -4,11 +4,19 @@
 metric (BASELINE.json): "closed-loop MPC steps/sec (batched MC trials, 4x4) + samples/sec set learning".
   value            = closed-loop UQ-RMPC steps/s, 4x4 system, Case_4-style Monte-Carlo (config C4): every rank runs
                      --trials trials x --horizon steps per bench step (weak scaling), trials keyed by global id.
-  set_learning     = secondary leg (config C2): halfspace max-reduction + homothety LP over pre-materialised
-                     information sets resident in HBM (2x2, N=20000 per set), samples/s.
+                     C4 converges to the origin: ~99 % of its steps only pass the ellipsoid test, so the QP-active
+                     legs below are reported beside it (qp_active: C4's transient, C1, C3), each with its own counters
+                     and a parity spot-check against the oracle.
+  set_learning     = config C2: halfspace max-reduction + homothety LP over pre-materialised information sets resident
+                     in HBM (2x2, N=20000 per set), samples/s, HBM roofline.
+  support_sweep    = config C5: h_S(d) over direction batches at s in {4 (the stored 4x4 loop), 10, 30} and 1M / 10M
+                     directions, fp64-vector roofline.
+  cpu_baseline     = the oracle (a CPU port, not MATLAB) on a bounded sample of the C4 workload: one thread and all
+                     host cores (OpenMP over trials), rank 0 at N=1 only.
 One JSON line on rank 0.  Launch: python bench.py [--gpus N --steps K --warmup W]  (N>1 under torch.distributed.run).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -25,6 +33,30 @@ import torch.distributed as dist
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X fp64 vector (non-MFMA) peak, BASELINE.md section 2.4
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+
+
+def executed_flops(cnt, nx, nu, nc, nz, nS, nH, trial_steps):
+    """fp64 arithmetic the closed-loop kernels execute, from the library's work counters (DESIGN.md "Kernel 3"):
+    per MPC step the set update (exact box: 2 nx products each for b_hat and W_A w), ellipsoid test and plant update;
+    per scan pass one fp64 pass over the S rows for 4 QPs; per trip of the one-QP-per-lane solver the nx x nx algebra
+    of 64 lanes; the 16-lane-row solver as in round 1."""
+    per_step = 2.0 * (3 * 2 * nx) + 2.0 * (nx * nx + nx) + 2.0 * nx * nu + 2.0 * nx * nx + 2.0 * nx * nu + 4.0 * nx
+    lane_trip = 2.0 * (nx * nx                          # rhs = C_A g
+                       + nx * (nx + 1) / 2 * nx         # M = C_A Ginv C_A'
+                       + nx * (nx - 1) * (nx + 1) / 6   # Cholesky updates
+                       + nx * (nx - 1)                  # two triangular solves
+                       + nx + nx * nx                   # delta, primal direction
+                       + 3 * nx) + 40.0                 # ratio test, updates; sqrt / divisions counted as one each
+    return (trial_steps * per_step
+            + (cnt["pivot_scans"] + cnt["lane_scans"]) * 4.0 * 2.0 * (nx + 1) * nS + cnt["h_passes"] * 2.0 * 2.0 * nz * nH
+            + cnt["solver_trips"] * 4.0 * 6.0 * nz * nz + cnt["lane_trips"] * 64.0 * lane_trip)
+
+
+def lib_sha256():
+    from lbmpc import _abi
+    with open(_abi.LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
 
 
 def main():
@@ -39,8 +71,9 @@ def main():
     ap.add_argument("--sl-sets", type=int, default=8192, help="information sets per GPU in the set-learning leg")
     ap.add_argument("--sl-n", type=int, default=20000, help="samples per information set")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-trials", type=int, default=2048)
+    ap.add_argument("--cpu-trials", type=int, default=1024, help="trials of the single-thread CPU leg (x8 for the all-cores leg)")
     ap.add_argument("--sweep-dirs", type=int, default=1000000)
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the qp_active (C1/C3/C4 transient) and the large sweep legs")
     ap.add_argument("--axis-aligned-proposal", action="store_true",
                     help="rejection-sample xi from the axis-aligned vertex box (the reference's proposal) instead of the principal-axes box")
     args = ap.parse_args()
@@ -49,7 +82,7 @@ def main():
     rank, world, local = ldist.init_process_group()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
-    core.init(local)
+    core.init()                      # the device the launcher bound (never device 0 by default)
     device = torch.device("cuda", local)
 
     def barrier():
@@ -57,15 +90,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def time_launches(fn, n, warm=1):
+        """n launches between HIP events on the launch stream -> mean ms"""
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
     # ---------------------------------------------------------------- primary leg: 4x4 closed-loop MC (C4)
     P = params.load(args.system)
-    nx, nz = int(P["nx"]), int(P["nx"]) + int(P["N"]) * int(P["nu"])
-    nS, nH = P["S_A"].shape[0], int(P["nc"]) * (int(P["Nu"]) + 1)
+    nx, nu_, nc_ = int(P["nx"]), int(P["nu"]), int(P["nc"])
+    nz = nx + int(P["N"]) * nu_
+    nS, nH = P["S_A"].shape[0], nc_ * (int(P["Nu"]) + 1)
     smp = params.sampler(P, oriented=not args.axis_aligned_proposal)   # same distribution on Xi, fewer rejections
     ctx = core.Context(P)
     x0 = np.zeros(nx)
     x0[0], x0[1] = -12.0, 5.0                      # Case_4...:27 x_RM_0, zero-padded
-    trial0, _ = args.trials * rank, None
+    trial0 = args.trials * rank
     bufs = dev.McBuffers(ctx, args.trials, device)
     mc_kw = dict(steps=args.horizon, card_I0=args.card_i0, seed=4, x0=x0, acc_bound=float(P["acc_bound"][0]),
                  distance_error=float(P["distance_error"][0]), trial0=trial0)
@@ -96,33 +143,70 @@ def main():
     total_steps = args.trials * world * args.horizon * args.steps
     value = total_steps / dt
     iters_local = int(bufs.qp_iters.sum().item())
-    # ALGORITHMIC flops of one launch on this GPU = the arithmetic the design executes, from the library's work counters
-    # (DESIGN.md "Kernel 3"): per MPC step the set update, tightening, ellipsoid test and plant update; per filtered
-    # wave-step one fp32 pass over the S rows for 64 trials; per full pivot scan one fp64 pass over the S rows for 4 QPs
-    # (+ one pass over the H rows for 2 QPs where the certificate does not skip it); per solver trip the O(nz^2) algebra.
     cnt = ctx.mc_counters()
-    nu_ = int(P["nu"]); nc_ = int(P["nc"])
-    per_step64 = 2.0 * (nx * nx + nx) + 2.0 * nx * nx + 2.0 * nc_ * nx + 8.0 * nx * nx + 2.0 * nx * nx + 4.0 * nx * nu_
-    exec64 = (args.trials * args.horizon * per_step64
-              + cnt["pivot_scans"] * 4.0 * 2.0 * (nx + 1) * nS + cnt["h_passes"] * 2.0 * 2.0 * nz * nH
-              + cnt["solver_trips"] * 4.0 * 6.0 * nz * nz)
+    exec64 = executed_flops(cnt, nx, nu_, nc_, nz, nS, nH, args.trials * args.horizon)
     exec32 = cnt["filter_wave_steps"] * 64.0 * 2.0 * (nx + 1) * nS
-    flops = exec64
-    achieved = flops / (kern_ms * 1e-3) / 1e12
+    achieved = exec64 / (kern_ms * 1e-3) / 1e12
     # what a solver without the pruning (one S pass per step + one full pass per active-set iteration) would
     # have to execute for the same results: reported for scale only, NOT a roofline position
     naive = args.trials * args.horizon * 2.0 * nS * nx + iters_local * 2.0 * (nS * nx + nH * nz)
     executed = {"fp64_flops_per_launch": exec64, "fp32_flops_per_launch": exec32, "counters": cnt,
                 "unpruned_equivalent_flops_per_launch": naive,
                 "unpruned_equivalent_tflops": naive / (kern_ms * 1e-3) / 1e12}
+    c4_ref = {k: getattr(bufs, k)[:256].cpu().numpy() for k in ("infeasible", "qp_iters", "alpha_final", "x_final")}
 
-    # ---------------------------------------------------------------- secondary leg: set learning (C2)
+    # ---------------------------------------------------------------- QP-active legs (rank-local, not aggregated)
+    qp_active = None
+    if not args.no_extra_legs:
+        import oracle_core
+        qp_active = {}
+
+        def qp_leg(name, Pq, x0q, trials, steps, card, seed, check_trials=48):
+            cq = core.Context(Pq)
+            sq = params.sampler(Pq, oriented=True)
+            bq = dev.McBuffers(cq, trials, device)
+            kw = dict(steps=steps, card_I0=card, seed=seed, x0=np.asarray(x0q, dtype=np.float64),
+                      acc_bound=float(np.ravel(Pq["acc_bound"])[0]), distance_error=float(np.ravel(Pq["distance_error"])[0]),
+                      trial0=0)
+            ms = time_launches(lambda: dev.mc_run(cq, sq, bq, **kw), max(5, args.steps), warm=2)
+            c = cq.mc_counters()
+            parity = None
+            if rank == 0:   # spot-check of the timed launch against the oracle on its first trials
+                o = oracle_core.Context(Pq).mc_run(sq, trials=check_trials, **kw)
+                assert np.array_equal(o["infeasible"], bq.infeasible[:check_trials].cpu().numpy()), name
+                assert np.array_equal(o["qp_iters"], bq.qp_iters[:check_trials].cpu().numpy()), name
+                assert np.array_equal(o["status"], bq.status[:check_trials].cpu().numpy()), name
+                assert np.allclose(o["alpha_final"], bq.alpha_final[:check_trials].cpu().numpy(), rtol=1e-9, atol=0), name
+                assert np.allclose(o["x_final"], bq.x_final[:check_trials].cpu().numpy(), rtol=1e-6, atol=1e-6), name
+                parity = f"first {check_trials} trials == oracle (flags, statuses, iteration counts exact; alpha 1e-9, x 1e-6)"
+            nxq, nuq, ncq = int(Pq["nx"]), int(Pq["nu"]), int(Pq["nc"])
+            nzq = nxq + int(Pq["N"]) * nuq
+            fl = executed_flops(c, nxq, nuq, ncq, nzq, Pq["S_A"].shape[0], ncq * (int(Pq["Nu"]) + 1), trials * steps)
+            out = {"workload": f"{trials} trials x {steps} steps, card(I0)={card}", "ms_per_launch": ms,
+                   "mpc_steps_per_s": trials * steps / (ms * 1e-3), "qp_solves_per_s": c["qp_solves"] / (ms * 1e-3),
+                   "counters": c, "executed_fp64_tflops": fl / (ms * 1e-3) / 1e12,
+                   "infeasible_trials": int(bq.infeasible.sum().item()), "max_status": int(bq.status.max().item()),
+                   "parity": parity}
+            cq.close()
+            return out
+
+        P1 = params.load(os.path.join(ROOT, "tests", "golden", "params_2x2.npz"))
+        qp_active["C1_2x2_case3"] = qp_leg("C1", P1, [-12.0, 5.0], 65536, 50, 100, 1)
+        P3 = params.load("3x3")
+        x03 = np.ravel(P3["x0_case5"]) if "x0_case5" in P3 else np.array([-12.0, 5.0, 0.0])
+        qp_active["C3_3x3_case5"] = qp_leg("C3", P3, x03, 10000, 20, 10, 5)
+        qp_active["C3_3x3_case5"]["x_RM_0"] = [float(t) for t in x03]
+        qp_active["C4_4x4_transient"] = qp_leg("C4t", P, x0, args.trials, 32, args.card_i0, 4)
+        qp_active["C4_4x4_transient"]["note"] = ("the first 32 steps of the C4 launch (pre-pass + transient kernel): every QP of "
+                                                 "C4 is solved here; the remaining steps pass the ellipsoid test")
+
+    # ---------------------------------------------------------------- set learning (C2)
     P2 = params.load(os.path.join(ROOT, "tests", "golden", "params_2x2.npz"))
     smp2 = params.sampler(P2)
     B, N = args.sl_sets, args.sl_n
     samples = torch.empty((B, N, 2), dtype=torch.float64, device=device)
     m = torch.empty((B, 4), dtype=torch.float64, device=device)
-    dev.sample_information_sets(smp2, P2["W_A"], N, B, seed=2, set0=B * rank, samples=samples, m=m)
+    gen_ms = time_launches(lambda: dev.sample_information_sets(smp2, P2["W_A"], N, B, seed=2, set0=B * rank, samples=samples, m=m), 2, warm=1)
     torch.cuda.synchronize()
     m_ref = m.clone()
     alpha = torch.empty(B, dtype=torch.float64, device=device)
@@ -132,10 +216,10 @@ def main():
         dev.halfspace_max(P2["W_A"], samples, out=m)
         dev.homothety_lp(P2["W_A"], P2["W_b"], m, alpha, v)
 
-    for _ in range(max(1, args.warmup)):
+    for _ in range(max(20, args.warmup)):   # the CPU-side parity checks above leave the GPU idle: bring the clocks back
         sl_step()
     barrier()
-    sl_steps = max(10, args.steps)
+    sl_steps = max(50, args.steps)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
@@ -154,67 +238,91 @@ def main():
     sl_bytes = B * N * 2 * 8.0
     sl_gbs = sl_bytes / (sl_ms * 1e-3) / 1e9
 
-    # ---------------------------------------------------------------- third leg: support sweep (C5)
-    # h_S(d) over 1M unit directions on the 4x4 system, s from the stored parameters' (s, alpha) loop at eps = 0.1
+    # ---------------------------------------------------------------- support sweep (C5)
     Phi4 = np.asarray(P["Phi"], dtype=np.float64)
     Wv = np.asarray(P["W_V"], dtype=np.float64)
-    nd = args.sweep_dirs
-    gen = torch.Generator(device=device); gen.manual_seed(5 + rank)
-    Dd = torch.randn((nd, nx), dtype=torch.float64, device=device, generator=gen)
-    Dd /= Dd.norm(dim=1, keepdim=True)
-    s_sw, a_sw = int(np.ravel(P["mrpi_s"])[0]), float(np.ravel(P["mrpi_alpha"])[0])
-    hout = torch.empty(nd, dtype=torch.float64, device=device)
-    for _ in range(max(1, args.warmup)):
-        dev.support_batch(Phi4, Wv, s_sw, a_sw, Dd, transpose=True, out=hout)
-    barrier()
-    sw_steps = max(10, args.steps)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(sw_steps):
-        dev.support_batch(Phi4, Wv, s_sw, a_sw, Dd, transpose=True, out=hout)
-    e1.record()
-    barrier()
-    sw_ms = e0.elapsed_time(e1) / sw_steps
     nV = Wv.shape[0]
-    sw_flops = nd * (s_sw * nV * (2.0 * nx + 1.0) + s_sw + 1.0)
-    sw_bytes = nd * 8.0 * (nx + 1)
-    sweep = {"value": nd * world / (sw_ms * 1e-3), "unit": "directions/s", "ms_per_step": sw_ms,
-             "config": {"workload": f"C5: 4x4 support sweep h_S(d), {nd} directions/GPU, s={s_sw}, nV={nV}"},
-             "roofline": {"bound": "valu_fp64", "achieved": sw_flops / (sw_ms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
-                          "unit": "TFLOP/s", "frac": sw_flops / (sw_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                          "hbm_GBps": sw_bytes / (sw_ms * 1e-3) / 1e9, "traffic": None, "kernel": "support_kernel",
-                          "algorithmic_flops_per_launch": sw_flops, "algorithmic_bytes_per_launch": sw_bytes}}
+    s_sw, a_sw = int(np.ravel(P["mrpi_s"])[0]), float(np.ravel(P["mrpi_alpha"])[0])
+
+    def sweep_leg(nd, s):
+        gen = torch.Generator(device=device); gen.manual_seed(5 + rank)
+        Dd = torch.randn((nd, nx), dtype=torch.float64, device=device, generator=gen)
+        Dd /= Dd.norm(dim=1, keepdim=True)
+        hout = torch.empty(nd, dtype=torch.float64, device=device)
+        ms = time_launches(lambda: dev.support_batch(Phi4, Wv, s, a_sw, Dd, transpose=True, out=hout), max(10, args.steps), warm=2)
+        fl = nd * (s * nV * (2.0 * nx + 1.0) + s + 1.0)
+        by = nd * 8.0 * (nx + 1)
+        tf = fl / (ms * 1e-3) / 1e12
+        return {"value": nd * world / (ms * 1e-3), "unit": "directions/s", "ms_per_step": ms,
+                "config": {"workload": f"C5: 4x4 support sweep h_S(d), {nd} directions/GPU, s={s}, nV={nV}"},
+                "roofline": {"bound": "valu_fp64", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": tf / FP64_VECTOR_PEAK_TFLOPS, "hbm_GBps": by / (ms * 1e-3) / 1e9, "traffic": None,
+                             "kernel": "support_kernel", "algorithmic_flops_per_launch": fl,
+                             "algorithmic_bytes_per_launch": by}}
+
+    sweep = sweep_leg(args.sweep_dirs, s_sw)
+    if not args.no_extra_legs:
+        sweep["other_sizes"] = {f"s{s}_nd{nd}": {k: leg[k] for k in ("value", "ms_per_step", "roofline")}
+                                for s in (4, 10, 30) for nd in (1000000, 10000000) for leg in [sweep_leg(nd, s)]}
+    barrier()
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1 only)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle_core
         octx = oracle_core.Context(P)
-        ct = args.cpu_trials
+        ct = min(args.cpu_trials, 256 * ((args.trials + 255) // 256))
+        kw0 = {**mc_kw, "trial0": 0}
         t0 = time.perf_counter()
-        o = octx.mc_run(smp, trials=ct, **{**mc_kw, "trial0": 0})
+        o = octx.mc_run(smp, trials=ct, **kw0)
         cdt = time.perf_counter() - t0
         # parity spot-check of the benchmarked launch against the oracle on the same trial ids
-        assert np.array_equal(o["infeasible"], bufs.infeasible[:ct].cpu().numpy())
-        assert np.array_equal(o["qp_iters"], bufs.qp_iters[:ct].cpu().numpy())
-        assert np.allclose(o["alpha_final"], bufs.alpha_final[:ct].cpu().numpy(), rtol=1e-9, atol=0)
-        assert np.allclose(o["x_final"], bufs.x_final[:ct].cpu().numpy(), rtol=1e-6, atol=1e-6)
-        cpu = {"value": ct * args.horizon / cdt, "unit": "MPC steps/s", "cores": 1, "kind": "port",
-               "sample": f"{ct} trials x {args.horizon} steps of the same {args.system} workload (trial ids 0..{ct - 1}), "
-                         f"oracle/lbmpc_oracle.c single thread, {cdt:.1f} s; parity of these trials checked against the GPU run",
+        n = min(ct, 256)
+        assert np.array_equal(o["infeasible"][:n], c4_ref["infeasible"][:n])
+        assert np.array_equal(o["qp_iters"][:n], c4_ref["qp_iters"][:n])
+        assert np.allclose(o["alpha_final"][:n], c4_ref["alpha_final"][:n], rtol=1e-9, atol=0)
+        assert np.allclose(o["x_final"][:n], c4_ref["x_final"][:n], rtol=1e-6, atol=1e-6)
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        threads = max(1, min(avail, int(os.environ.get("OMP_NUM_THREADS", avail))))
+        ct_all = ct * min(threads, 8)
+        t0 = time.perf_counter()
+        o2 = octx.mc_run(smp, trials=ct_all, threads=threads, **kw0)
+        cdt_all = time.perf_counter() - t0
+        assert np.array_equal(o2["qp_iters"][:ct], o["qp_iters"])
+        model = "unknown"
+        try:
+            with open("/proc/cpuinfo") as f:
+                model = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+        except (OSError, StopIteration):
+            pass
+        cpu = {"value": ct_all * args.horizon / cdt_all, "unit": "MPC steps/s", "cores": threads, "kind": "port",
+               "sample": f"{ct_all} trials x {args.horizon} steps of the same {args.system} workload (trial ids 0..{ct_all - 1}), "
+                         f"oracle/lbmpc_oracle.c, OpenMP over trials on {threads} threads, {cdt_all:.1f} s; the first {n} trials "
+                         f"checked against the GPU run",
+               "single_thread": {"value": ct * args.horizon / cdt, "cores": 1,
+                                 "sample": f"{ct} trials x {args.horizon} steps, one thread, {cdt:.1f} s"},
+               "cpu_model": model, "host_cpus_visible": avail,
+               "note": "CPU restatement (plain C, no pruning), not MATLAB; the reference's only published figure is "
+                       "15.4 MPC steps/s (2x2, MATLAB+CasADi/IPOPT, hardware unknown, Results_3_small.mat)",
                "reference_stored_matlab_steps_per_s": 15.4}
-    # HBM traffic per launch from the committed PMC pass (tools/profile_round.sh), valid for the default sizes only
-    traffic_mc = traffic_sl = None
+    # HBM traffic per launch from the committed PMC pass of THIS library build (tools/profile_round.sh writes the
+    # library's sha256 into the summary); anything else is reported as null rather than as a stale number
+    traffic_mc = traffic_sl = traffic_src = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
-            pk = json.load(f)["kernels"]
-        if (B, N) == (8192, 20000):
-            k2 = next(v for k, v in pk.items() if "halfspace_max_kernel" in k)
-            traffic_sl = k2.get("hbm_read_bytes", 0.0) + k2.get("hbm_write_bytes", 0.0)
-        if (args.trials, args.horizon, args.system) == (131072, 1000, "4x4"):
-            mck = {k: v for k, v in pk.items() if "mc_" in k}
-            nl = min(v["launches"] for v in mck.values())   # profiled bench steps (mc_kernel runs twice per step)
-            traffic_mc = sum((v.get("hbm_read_bytes", 0.0) + v.get("hbm_write_bytes", 0.0)) * v["launches"] / nl for v in mck.values())
+        with open(PMC_SUMMARY) as f:
+            pj = json.load(f)
+        if pj.get("library_sha256") == lib_sha256():
+            pk = pj["kernels"]
+            traffic_src = "profiles/" + os.path.basename(PMC_SUMMARY) + " (separate rocprofv3 --pmc passes of this library build, default sizes)"
+            if (B, N) == (8192, 20000):
+                k2 = next(v for k, v in pk.items() if "halfspace_max_kernel" in k)
+                traffic_sl = k2.get("hbm_read_bytes", 0.0) + k2.get("hbm_write_bytes", 0.0)
+            if (args.trials, args.horizon, args.system) == (131072, 1000, "4x4"):
+                mck = {k: v for k, v in pk.items() if "mc_" in k}
+                traffic_mc = pj.get("mc_bytes_per_bench_step")
     except (OSError, KeyError, StopIteration, ValueError):
         pass
     if rank == 0:
@@ -224,23 +332,31 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"C4: {args.system} UQ-RMPC closed-loop Monte-Carlo, {args.trials} trials/GPU x "
-                                   f"{args.horizon} steps, card(I0)={args.card_i0}, build-generated params_{args.system}.npz",
+                                   f"{args.horizon} steps, card(I0)={args.card_i0}, build-generated params_{args.system}.npz "
+                                   f"(the reference's 4x4 blob is missing: parity vs the CPU oracle only)",
                        "trials_per_gpu": args.trials, "horizon": args.horizon, "nS": int(nS), "nH": int(nH), "nz": int(nz),
                        "parallelism": f"trial-sharded x{world}, no data-path collective",
                        "xi_proposal": "axis-aligned box" if args.axis_aligned_proposal else "principal-axes box"},
             "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic_mc, "kernel": "mc_sample_kernel + mc_kernel (transient) + mc_steady_kernel",
-                         "kernel_ms": kern_ms, "algorithmic_flops_per_launch": flops, "executed": executed,
+                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic_mc, "traffic_source": traffic_src,
+                         "kernel": "mc_sample_kernel + mc_kernel (transient) + mc_steady_kernel",
+                         "kernel_ms": kern_ms, "algorithmic_flops_per_launch": exec64, "executed": executed,
+                         "qp_solves_per_s_whole_launch": cnt["qp_solves"] / (kern_ms * 1e-3),
                          "note": "MFMA deliberately unused (north_star); bound is the fp64 vector rate. achieved prices the fp64 "
                                  "arithmetic the kernels of one step (pre-pass, transient, steady state; timed together) execute, counted by "
                                  "the library's work counters; the path is instruction-issue/latency bound (DESIGN.md), most "
                                  "instructions are bookkeeping, not flops. 'unpruned_equivalent' is what a solver without the "
                                  "exact pruning (ellipsoid test, H-row certificate, candidate pivots) would execute"},
+            "qp_active": qp_active,
             "set_learning": {"value": sl_value, "unit": "samples/s", "ms_per_step": sl_ms,
                              "config": {"workload": f"C2: 2x2 set learning, {B} information sets/GPU x {N} samples resident in HBM"},
                              "roofline": {"bound": "hbm", "achieved": sl_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                          "frac": sl_gbs / HBM_PEAK_GBS, "traffic": traffic_sl, "kernel": "halfspace_max_kernel",
-                                          "algorithmic_bytes_per_launch": sl_bytes}},
+                                          "frac": sl_gbs / HBM_PEAK_GBS, "traffic": traffic_sl, "traffic_source": traffic_src,
+                                          "kernel": "halfspace_max_kernel", "algorithmic_bytes_per_launch": sl_bytes},
+                             "generate_mode": {"kernel": "sample_sets_kernel", "ms_per_launch": gen_ms,
+                                               "samples_per_s": B * N / (gen_ms * 1e-3),
+                                               "write_GBps": sl_bytes / (gen_ms * 1e-3) / 1e9,
+                                               "note": "Philox + rejection sampling, VALU/int-bound (3 Philox4x32-10 blocks per sample), writes each sample once"}},
             "support_sweep": sweep,
             "mc_stats": {"infeasible_trials": int(infeas.sum().item()), "max_status": int(status.max().item()),
                          "mean_qp_iters_per_trial": float(iters.double().mean().item())},

@@ -818,10 +818,9 @@ int orc_uqmpc_step(orc_ctx* c, int64_t batch, int uq_update, const double* x, co
 
 /* Closed-loop Monte-Carlo: Case_3...:57-88, Case_4...:32-66, Case_5...:55-98 in relative
  * coordinates (SURVEY.md hard part 5). */
-int orc_mc_run(orc_ctx* c, const lbmpc_sampler* smp, const lbmpc_mc_cfg* cfg, lbmpc_mc_out* out) {
-    if (!c || !smp || !cfg || !out || !cfg->x0) return LBMPC_ERR_ARG;
+static void mc_trial(const orc_ctx* c, const lbmpc_sampler* smp, const lbmpc_mc_cfg* cfg, lbmpc_mc_out* out, int64_t t) {
     int nx = c->nx, nu = c->nu, nW = c->nW, K = cfg->steps;
-    for (int64_t t = 0; t < cfg->trials; ++t) {
+    {
         uint64_t tid = (uint64_t)(cfg->trial0 + t);
         int status = 0, infeasible = 0, iters_total = 0;
         int hint[LBMPC_MAX_NZ], nhint = 0; /* active set of the previous step's QP (pivot candidates) */
@@ -893,5 +892,19 @@ int orc_mc_run(orc_ctx* c, const lbmpc_sampler* smp, const lbmpc_mc_cfg* cfg, lb
         if (out->v_final) memcpy(out->v_final + (size_t)t * nx, v, sizeof(double) * nx);
         if (out->x_final) memcpy(out->x_final + (size_t)t * nx, x, sizeof(double) * nx);
     }
+}
+
+int orc_mc_run(orc_ctx* c, const lbmpc_sampler* smp, const lbmpc_mc_cfg* cfg, lbmpc_mc_out* out) {
+    if (!c || !smp || !cfg || !out || !cfg->x0) return LBMPC_ERR_ARG;
+    for (int64_t t = 0; t < cfg->trials; ++t) mc_trial(c, smp, cfg, out, t);
+    return 0;
+}
+
+/* The same loop with the independent trials spread over `threads` host threads (OpenMP): the all-cores leg of
+ * bench.py's cpu_baseline.  Results are those of orc_mc_run (no shared state between trials). */
+int orc_mc_run_omp(orc_ctx* c, const lbmpc_sampler* smp, const lbmpc_mc_cfg* cfg, lbmpc_mc_out* out, int threads) {
+    if (!c || !smp || !cfg || !out || !cfg->x0 || threads < 1) return LBMPC_ERR_ARG;
+#pragma omp parallel for schedule(dynamic, 8) num_threads(threads)
+    for (int64_t t = 0; t < cfg->trials; ++t) mc_trial(c, smp, cfg, out, t);
     return 0;
 }

@@ -114,7 +114,8 @@ class Context:
         return o
 
     def mc_run(self, sampler, trials, steps, card_I0, seed, x0, acc_bound, distance_error, trial0=0, traj_trials=0,
-               sampler_max_attempts=1000):
+               sampler_max_attempts=1000, threads=1):
+        """threads > 1: the trials are spread over that many host threads (OpenMP); same results"""
         nx, nu = self.nx, self.nu
         x0 = fcol(x0).ravel()
         R = min(traj_trials, trials)
@@ -127,6 +128,9 @@ class Context:
                          traj_trials=R, sampler_max_attempts=sampler_max_attempts)
         out = _abi.McOut(**{k: (v.ctypes.data_as(_abi.c_int32_p) if v.dtype == np.int32 else dptr(v))
                             for k, v in o.items()})
-        rc = self.lib.orc_mc_run(self.handle, sampler.ref(), C.byref(cfg), C.byref(out))
+        if threads > 1:
+            rc = self.lib.orc_mc_run_omp(self.handle, sampler.ref(), C.byref(cfg), C.byref(out), int(threads))
+        else:
+            rc = self.lib.orc_mc_run(self.handle, sampler.ref(), C.byref(cfg), C.byref(out))
         assert rc == 0, rc
         return o

@@ -25,5 +25,7 @@ def load():
         lib.orc_homothety_lp_enum.restype = ci
         lib.orc_ctx_export.argtypes = [C.c_void_p, dp, dp, dp, dp]
         lib.orc_ctx_export.restype = ci
+        lib.orc_mc_run_omp.argtypes = [C.c_void_p, C.POINTER(_abi.Sampler), C.POINTER(_abi.McCfg), C.POINTER(_abi.McOut), ci]
+        lib.orc_mc_run_omp.restype = ci
         _lib = lib
     return _lib

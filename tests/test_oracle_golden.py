@@ -285,3 +285,17 @@ def test_upstream_hs_pins_s_alpha_and_support_sum():
     assert (s, rc) == (13, 0) and abs(a - 0.005321295948) < 1e-11
     h = oracle_core.support_batch(U["Phi"], U["W_V"], s, a, Fc.T, transpose=True)
     np.testing.assert_allclose(h, U["hs"].ravel(), atol=1.5e-8)
+
+
+def test_oracle_openmp_leg_equals_serial():
+    """the all-cores CPU baseline (OpenMP over trials) returns exactly what the serial loop returns"""
+    import oracle_core
+    from lbmpc import _abi
+    P = fixtures.params_dict()
+    smp = _abi.make_sampler(**fixtures.sampler_args(P))
+    c = oracle_core.Context(P)
+    kw = dict(trials=97, steps=8, card_I0=10, seed=3, x0=[-12.0, 5.0], acc_bound=2.0, distance_error=15.0, traj_trials=97)
+    a, b = c.mc_run(smp, **kw), c.mc_run(smp, threads=4, **kw)
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    c.close()
