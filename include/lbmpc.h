@@ -280,6 +280,36 @@ int lbmpc_mc_run(lbmpc_ctx* ctx, const lbmpc_sampler* smp, const lbmpc_mc_cfg* c
 int lbmpc_mc_run_dev(lbmpc_ctx* ctx, const lbmpc_sampler* smp, const lbmpc_mc_cfg* cfg,
                      lbmpc_mc_out* out_dev, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * One node, several GPUs, inside one process (the MATLAB drop-in is a single process)
+ * ---------------------------------------------------------------------------------------- */
+
+/* One controller context per device, built from the same parameters (devices: ngpu indices, NULL = 0..ngpu-1;
+ * every listed device is validated as lbmpc_init does).  No counterpart in the reference, whose only parallel
+ * construct is `parfor` (Functions_general/MRPISet.m:110); SURVEY.md 8e. */
+typedef struct lbmpc_multi lbmpc_multi;
+int lbmpc_multi_create(const lbmpc_params* p, const int* devices, int ngpu, lbmpc_multi** out);
+void lbmpc_multi_destroy(lbmpc_multi* m);
+int lbmpc_multi_ngpu(const lbmpc_multi* m);
+/* The contiguous block partition used by every sharded entry point (and by the one-process-per-GPU driver,
+ * lbmpc/dist.py): shard `rank` of `world` gets [first, first + count), sizes differ by at most one.  Needs no device. */
+int lbmpc_block_shard(int64_t total, int rank, int world, int64_t* first, int64_t* count);
+
+/* lbmpc_mc_run over the devices of `m`: contiguous block shards of the trials (device g of G runs trials
+ * [g*T/G, (g+1)*T/G) of cfg, keyed by their global ids cfg->trial0 + ...), one host thread per device, no exchange
+ * during the closed loop; every device copies its shard into the caller's HOST arrays.  Results are bitwise those of
+ * lbmpc_mc_run on one device.  Replaces the serial Monte-Carlo loops of Cases_general/Case_4...:32-74,
+ * Case_5...:55-98. */
+int lbmpc_multi_mc_run(lbmpc_multi* m, const lbmpc_sampler* smp, const lbmpc_mc_cfg* cfg, lbmpc_mc_out* out);
+
+/* lbmpc_halfspace_max with every information set sharded BY SAMPLE over ngpu devices: local max-reductions, then
+ * ONE all-reduce(max) of batch*nW doubles over RCCL (ncclCommInitAll in-process; librccl is loaded on first use),
+ * bit-identical to a single device.  Host pointers.  Replaces the sample rows of
+ * Functions_general/InitialSetComputation.m:77-79 for information sets too large for, or already spread over,
+ * several GPUs. */
+int lbmpc_halfspace_max_multi(const double* WA, int nW, int nx, const double* samples, int64_t N, int64_t batch,
+                              int64_t batch_stride, double* m_out, const int* devices, int ngpu);
+
 /* Work counters of the last lbmpc_mc_run / lbmpc_mc_run_dev on this context (synchronises the device).  No
  * counterpart in the reference (its loops are timed with tic/toc, Case_3...:57,69); used by bench.py to state the
  * arithmetic that was actually executed.  out[0] wave-steps whose rows were scanned by the fp32 filter (64 trials

@@ -155,6 +155,13 @@ def declare(lib, prefix):
         for name in ["support_batch", "halfspace_max", "sample_information_sets", "homothety_lp", "mc_run"]:
             f = getattr(lib, prefix + name + "_dev")
             f.argtypes, f.restype = sig[name] + [vp], ci
+        lib.lbmpc_multi_create.argtypes, lib.lbmpc_multi_create.restype = [C.POINTER(Params), ip, ci, C.POINTER(vp)], ci
+        lib.lbmpc_multi_destroy.argtypes, lib.lbmpc_multi_destroy.restype = [vp], None
+        lib.lbmpc_multi_ngpu.argtypes, lib.lbmpc_multi_ngpu.restype = [vp], ci
+        lib.lbmpc_multi_mc_run.argtypes, lib.lbmpc_multi_mc_run.restype = sig["mc_run"], ci
+        lib.lbmpc_halfspace_max_multi.argtypes, lib.lbmpc_halfspace_max_multi.restype = sig["halfspace_max"] + [ip, ci], ci
+        lib.lbmpc_block_shard.argtypes = [i64, ci, ci, C.POINTER(i64), C.POINTER(i64)]
+        lib.lbmpc_block_shard.restype = ci
         lib.lbmpc_halfspace_max_noalloc.argtypes, lib.lbmpc_halfspace_max_noalloc.restype = sig["halfspace_max"] + [vp], ci
         lib.lbmpc_mc_counters.argtypes, lib.lbmpc_mc_counters.restype = [vp, C.POINTER(C.c_uint64)], ci
         lib.lbmpc_version.restype = ci

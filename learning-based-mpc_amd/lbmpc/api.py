@@ -77,11 +77,16 @@ def reference_directions(nx, rng):
     return np.vstack(D)
 
 
-def MRPISet(Ak, W, epsilon, template_directions=None, mode=_abi.MS_MAX_LITERAL, seed=0, return_info=False):
+def MRPISet(Ak, W, epsilon, template_directions=None, mode=_abi.MS_RAKOVIC, seed=0, return_info=False):
     """epsilon-outer mRPI set of x+ = Ak x + w, w in W.  (s, alpha) by the loop of MRPISet.m:27-63 on the device;
     the set itself is returned as the H-rep template polytope {x : d_j' x <= h_S(d_j)} of the exact Minkowski-sum
     support (1-alpha)^-1 sum_{t<s} h_W((Ak^t)' d), evaluated by the batched support kernel, instead of the
-    reference's hull of 200*nx SOCP-projected random samples (MRPISet.m:66-136; SURVEY.md hard part 4)."""
+    reference's hull of 200*nx SOCP-projected random samples (MRPISet.m:66-136; SURVEY.md hard part 4).
+    mode: the default is the Rakovic form (alpha from h_W((Ak^s)' f_j), Ms from the transposed sums): it is the one
+    for which (1-alpha)^-1 (+)_{t<s} Ak^t W is an epsilon-outer approximation, and the one consistent with the
+    transposed sum evaluated below.  The reference's literal loops (MS_MAX_LITERAL: MRPISet.m:29,43 use A^s f_j and
+    A^i d without the transpose; MS_SUM_LITERAL: Functions/MRPISet.m:8-17) remain selectable, e.g. to reproduce the
+    (s, alpha) behind a stored parameter set.  Template directions are drawn from a seeded generator."""
     Ak = np.asarray(Ak, dtype=np.float64)
     nx = Ak.shape[0]
     rng = np.random.default_rng(seed)

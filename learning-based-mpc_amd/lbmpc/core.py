@@ -73,6 +73,32 @@ def halfspace_max(WA, samples):
     return m[0] if single else m
 
 
+def halfspace_max_multi(WA, samples, devices):
+    """halfspace_max with every set sharded by sample over `devices` (list of device indices): local reductions, one
+    RCCL all-reduce(max) inside the library"""
+    lib = _abi.load()
+    WA = fcol(WA)
+    nW, nx = WA.shape
+    S = np.asarray(samples, dtype=np.float64)
+    single = S.ndim == 2
+    if single:
+        S = S[None]
+    batch, _, N = S.shape
+    flat = np.ascontiguousarray(np.transpose(S, (0, 2, 1)))
+    m = np.zeros((batch, nW))
+    dv = (C.c_int * len(devices))(*devices)
+    _chk(lib.lbmpc_halfspace_max_multi(dptr(WA), nW, nx, dptr(flat), N, batch, N * nx, dptr(m), dv, len(devices)),
+         "lbmpc_halfspace_max_multi")
+    return m[0] if single else m
+
+
+def block_shard(total, rank, world):
+    lib = _abi.load()
+    a, b = C.c_int64(0), C.c_int64(0)
+    _chk(lib.lbmpc_block_shard(int(total), int(rank), int(world), C.byref(a), C.byref(b)), "lbmpc_block_shard")
+    return a.value, b.value
+
+
 def sample_information_sets(sampler, WA, N, batch, seed, set0=0, max_attempts=100, want_samples=True):
     lib = init()
     WA = fcol(WA)
@@ -181,4 +207,47 @@ class Context:
         out = _abi.McOut(**{k: (v.ctypes.data_as(_abi.c_int32_p) if v.dtype == np.int32 else dptr(v))
                             for k, v in o.items()})
         _chk(self.lib.lbmpc_mc_run(self.handle, sampler.ref(), C.byref(cfg), C.byref(out)), "lbmpc_mc_run")
+        return o
+
+
+class MultiContext:
+    """One controller context per device inside this process (lbmpc_multi_create); mc_run shards the trials over them."""
+
+    def __init__(self, params_dict, devices):
+        self.lib = _abi.load()
+        self.keep = _abi.make_params(params_dict)
+        self.handle = C.c_void_p()
+        dv = (C.c_int * len(devices))(*devices)
+        rc = self.lib.lbmpc_multi_create(self.keep.ref(), dv, len(devices), C.byref(self.handle))
+        if rc != 0:
+            raise LbmpcError(rc, "lbmpc_multi_create")
+        p = self.keep.struct
+        self.nx, self.nu = p.nx, p.nu
+
+    def close(self):
+        if self.handle:
+            self.lib.lbmpc_multi_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def mc_run(self, sampler, trials, steps, card_I0, seed, x0, acc_bound, distance_error, trial0=0, traj_trials=0,
+               sampler_max_attempts=1000):
+        nx, nu = self.nx, self.nu
+        x0 = fcol(x0).ravel()
+        R = min(traj_trials, trials)
+        o = dict(infeasible=np.zeros(trials, np.int32), status=np.zeros(trials, np.int32),
+                 qp_iters=np.zeros(trials, np.int32), alpha_final=np.zeros(trials), v_final=np.zeros((trials, nx)),
+                 alpha0=np.zeros(trials), x_final=np.zeros((trials, nx)), traj_x=np.zeros((R, steps + 1, nx)),
+                 traj_u=np.zeros((R, steps, nu)), traj_alpha=np.zeros((R, steps + 1)), traj_s0=np.zeros((R, steps, nx)))
+        cfg = _abi.McCfg(trials=trials, trial0=trial0, steps=steps, card_I0=card_I0, seed=seed, x0=dptr(x0),
+                         acc_bound=float(acc_bound), distance_error=float(distance_error),
+                         traj_trials=R, sampler_max_attempts=sampler_max_attempts)
+        out = _abi.McOut(**{k: (v.ctypes.data_as(_abi.c_int32_p) if v.dtype == np.int32 else dptr(v))
+                            for k, v in o.items()})
+        _chk(self.lib.lbmpc_multi_mc_run(self.handle, sampler.ref(), C.byref(cfg), C.byref(out)), "lbmpc_multi_mc_run")
         return o

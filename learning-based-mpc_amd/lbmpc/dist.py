@@ -29,7 +29,8 @@ def init_process_group(backend=None):
 
 
 def block_shard(total, rank, world):
-    """contiguous block partition -> (first, count); sizes differ by at most one"""
+    """contiguous block partition -> (first, count); sizes differ by at most one (same rule as the library's
+    lbmpc_block_shard, which the in-process multi-GPU entry points use; tests compare the two)"""
     q, r = divmod(int(total), int(world))
     first = rank * q + min(rank, r)
     return first, q + (1 if rank < r else 0)

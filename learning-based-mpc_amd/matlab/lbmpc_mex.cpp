@@ -4,10 +4,13 @@
 //
 // Built where MATLAB exists with
 //   mex -R2018a lbmpc_mex.cpp -I../../include -L../csrc -llbmpc_hip
-// (no mex.h in the build image: this file is compiled and exercised only on a MATLAB host; the same C ABI is
-// what tests/ drive through ctypes).  MATLAB owns every input mxArray (read-only via mxGetDoubles); outputs
-// are allocated with mxCreateDoubleMatrix and filled by the library.  Controller contexts are returned as
+// The build image has no MATLAB: there this file is compiled against the stand-in mex.h of tests/mex_stub/ and its
+// mexFunction is driven by tests/test_mex_gateway.py (argument order, plhs handling, struct marshalling, error
+// mapping) -- the real mex build is unverified.  MATLAB owns every input mxArray (read-only via mxGetDoubles);
+// outputs are allocated with mxCreateDoubleMatrix and filled by the library.  Controller contexts are returned as
 // uint64 handles, freed by 'destroy' / mexAtExit; the MEX file stays locked while any context lives.
+//   lbmpc_mex('init', device)            optional, before anything else: GPU for the single-device calls (default 0)
+//   h = lbmpc_mex('create', p [, ngpu])  ngpu > 1: 'mc_run' on this handle shards its trials over GPUs 0..ngpu-1
 #include <cstdint>
 #include <cstring>
 #include <set>
@@ -16,14 +19,23 @@
 #include "lbmpc.h"
 #include "mex.h"
 
-static std::set<lbmpc_ctx*> g_live;
+struct Handle {            // what a uint64 handle points to
+    lbmpc_ctx* ctx = nullptr;      // single-device context ('step', 'mc_run' with one GPU)
+    lbmpc_multi* multi = nullptr;  // one context per device ('mc_run' with ngpu > 1)
+};
+static std::set<Handle*> g_live;
 static bool g_init = false;
 
 static void fail(const char* id, int rc) {
     mexErrMsgIdAndTxt(id, "lbmpc error %d: %s", rc, lbmpc_last_error());
 }
+static void release(Handle* h) {
+    if (h->ctx) lbmpc_destroy(h->ctx);
+    if (h->multi) lbmpc_multi_destroy(h->multi);
+    delete h;
+}
 static void at_exit() {
-    for (lbmpc_ctx* c : g_live) lbmpc_destroy(c);
+    for (Handle* h : g_live) release(h);
     g_live.clear();
 }
 static const double* dbl(const mxArray* a) { return mxGetDoubles(a); }
@@ -35,7 +47,15 @@ static const mxArray* field(const mxArray* s, const char* name) {
     return f;
 }
 static int ifield(const mxArray* s, const char* name) { return (int)mxGetScalar(field(s, name)); }
-static lbmpc_ctx* handle(const mxArray* a) { return reinterpret_cast<lbmpc_ctx*>(*reinterpret_cast<uint64_t*>(mxGetData(a))); }
+static Handle* handle(const mxArray* a) {
+    if (!a || mxGetClassID(a) != mxUINT64_CLASS || mxIsEmpty(a)) mexErrMsgIdAndTxt("lbmpc:handle", "expected a uint64 context handle");
+    Handle* h = reinterpret_cast<Handle*>(*reinterpret_cast<uint64_t*>(mxGetData(a)));
+    if (!g_live.count(h)) mexErrMsgIdAndTxt("lbmpc:handle", "stale or foreign context handle");
+    return h;
+}
+static void need_args(int nrhs, int n, const char* usage) {
+    if (nrhs < n) mexErrMsgIdAndTxt("lbmpc:usage", "%s", usage);
+}
 
 static void fill_sampler(const mxArray* s, lbmpc_sampler* o) {
     o->nx = ifield(s, "nx"); o->nu = ifield(s, "nu");
@@ -53,15 +73,18 @@ static void fill_sampler(const mxArray* s, lbmpc_sampler* o) {
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     if (nrhs < 1 || !mxIsChar(prhs[0])) mexErrMsgIdAndTxt("lbmpc:usage", "lbmpc_mex(cmd, ...)");
     char cmdbuf[64];
-    mxGetString(prhs[0], cmdbuf, sizeof cmdbuf);
+    if (mxGetString(prhs[0], cmdbuf, sizeof cmdbuf)) mexErrMsgIdAndTxt("lbmpc:usage", "command name too long");
     const std::string cmd(cmdbuf);
-    if (!g_init) {
-        int rc = lbmpc_init(0);
+    if (!g_init || cmd == "init") {
+        const int device = (cmd == "init" && nrhs > 1) ? (int)mxGetScalar(prhs[1]) : 0;
+        int rc = lbmpc_init(device);
         if (rc) fail("lbmpc:init", rc);
-        mexAtExit(at_exit);
+        if (!g_init) mexAtExit(at_exit);
         g_init = true;
+        if (cmd == "init") return;
     }
     if (cmd == "support_batch") {  // h = lbmpc_mex('support_batch', A, Vw, s, alpha, D, transpose)
+        need_args(nrhs, 7, "h = lbmpc_mex('support_batch', A, Vw, s, alpha, D, transpose)");
         const int nx = rows(prhs[1]);
         const int64_t nd = cols(prhs[5]);
         plhs[0] = mxCreateDoubleMatrix(nd, 1, mxREAL);
@@ -69,16 +92,20 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
                                      mxGetScalar(prhs[4]), dbl(prhs[5]), nd, (int)mxGetScalar(prhs[6]), mxGetDoubles(plhs[0]));
         if (rc < 0) fail("lbmpc:support_batch", rc);
     } else if (cmd == "mrpi_s_alpha") {  // [s, alpha, Ms] = lbmpc_mex('mrpi_s_alpha', A, Vw, WA, Wb, Dirs, eps, mode)
+        need_args(nrhs, 8, "[s, alpha, Ms] = lbmpc_mex('mrpi_s_alpha', A, Vw, WA, Wb, Dirs, eps, mode)");
         int s = 0; double alpha = 0, Ms = 0;
         int rc = lbmpc_mrpi_s_alpha(dbl(prhs[1]), rows(prhs[1]), dbl(prhs[2]), rows(prhs[2]), dbl(prhs[3]), dbl(prhs[4]),
                                     rows(prhs[3]), dbl(prhs[5]), cols(prhs[5]), mxGetScalar(prhs[6]), (int)mxGetScalar(prhs[7]),
                                     60, &s, &alpha, &Ms);
         if (rc < 0) fail("lbmpc:mrpi_s_alpha", rc);
+        if (rc > 0) mexErrMsgIdAndTxt("lbmpc:mrpi_s_alpha", "the (s, alpha) search hit its iteration cap at s = %d, alpha = %g", s, alpha);
         plhs[0] = mxCreateDoubleScalar(s);
         if (nlhs > 1) plhs[1] = mxCreateDoubleScalar(alpha);
         if (nlhs > 2) plhs[2] = mxCreateDoubleScalar(Ms);
     } else if (cmd == "learn_set") {  // [alpha, v, status] = lbmpc_mex('learn_set', WA, Wb, samples)  samples nx x N
+        need_args(nrhs, 4, "[alpha, v, status] = lbmpc_mex('learn_set', WA, Wb, samples)");
         const int nW = rows(prhs[1]), nx = cols(prhs[1]);
+        if (nW > LBMPC_MAX_NW) mexErrMsgIdAndTxt("lbmpc:learn_set", "W has %d rows (limit %d)", nW, LBMPC_MAX_NW);
         double m[LBMPC_MAX_NW];
         int rc = lbmpc_halfspace_max(dbl(prhs[1]), nW, nx, dbl(prhs[3]), cols(prhs[3]), 1, 0, m);
         if (rc < 0) fail("lbmpc:halfspace_max", rc);
@@ -90,6 +117,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         if (nlhs > 1) plhs[1] = v;
         if (nlhs > 2) plhs[2] = mxCreateDoubleScalar(st);
     } else if (cmd == "sample_sets") {  // [samples, m] = lbmpc_mex('sample_sets', sampler, WA, N, seed, set0)
+        need_args(nrhs, 6, "[samples, m] = lbmpc_mex('sample_sets', sampler, WA, N, seed, set0)");
         lbmpc_sampler smp; fill_sampler(prhs[1], &smp);
         const int nW = rows(prhs[2]);
         const int64_t N = (int64_t)mxGetScalar(prhs[3]);
@@ -100,7 +128,9 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         if (rc < 0) fail("lbmpc:sample_sets", rc);
         if (nlhs > 1) plhs[1] = m;
     } else if (cmd == "create") {  // h = lbmpc_mex('create', p)  p: struct with the lbmpc_params fields (A,b unpacked)
+        need_args(nrhs, 2, "h = lbmpc_mex('create', p [, ngpu])");
         const mxArray* s = prhs[1];
+        const int ngpu = nrhs > 2 ? (int)mxGetScalar(prhs[2]) : 1;
         lbmpc_params p;
         p.nx = ifield(s, "nx"); p.nu = ifield(s, "nu"); p.N = ifield(s, "N"); p.nc = ifield(s, "nc"); p.Nu = ifield(s, "Nu");
         p.nS = rows(field(s, "S_A")); p.nW = rows(field(s, "W_A"));
@@ -108,20 +138,26 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         p.Px = dbl(field(s, "Px")); p.Pc = dbl(field(s, "Pc")); p.F = dbl(field(s, "F")); p.G = dbl(field(s, "G"));
         p.F_bar = dbl(field(s, "F_bar")); p.Psi = dbl(field(s, "Psi")); p.S_A = dbl(field(s, "S_A")); p.S_b = dbl(field(s, "S_b"));
         p.W_A = dbl(field(s, "W_A")); p.W_b = dbl(field(s, "W_b")); p.hs = dbl(field(s, "hs"));
-        lbmpc_ctx* c = nullptr;
-        int rc = lbmpc_uqmpc_create(&p, &c);
-        if (rc) fail("lbmpc:create", rc);
-        g_live.insert(c);
+        Handle* h = new Handle();
+        int rc = lbmpc_uqmpc_create(&p, &h->ctx);
+        if (!rc && ngpu > 1) rc = lbmpc_multi_create(&p, nullptr, ngpu, &h->multi);
+        if (rc) { release(h); fail("lbmpc:create", rc); }
+        g_live.insert(h);
         if (g_live.size() == 1) mexLock();
         plhs[0] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL);
-        *reinterpret_cast<uint64_t*>(mxGetData(plhs[0])) = reinterpret_cast<uint64_t>(c);
+        *reinterpret_cast<uint64_t*>(mxGetData(plhs[0])) = reinterpret_cast<uint64_t>(h);
     } else if (cmd == "destroy") {
-        lbmpc_ctx* c = handle(prhs[1]);
-        if (g_live.erase(c)) { lbmpc_destroy(c); if (g_live.empty()) mexUnlock(); }
+        need_args(nrhs, 2, "lbmpc_mex('destroy', h)");
+        Handle* h = handle(prhs[1]);
+        g_live.erase(h);
+        release(h);
+        if (g_live.empty()) mexUnlock();
     } else if (cmd == "step") {
         // [s0, u, alpha, v, hk, Sb_hat, Wb_hat, status] = lbmpc_mex('step', h, uq, dims, x, alpha_prev, v_prev, w_new)
-        lbmpc_ctx* c = handle(prhs[1]);
+        need_args(nrhs, 7, "[s0, u, alpha, v, hk, Sb_hat, Wb_hat, status] = lbmpc_mex('step', h, uq, dims, x, alpha_prev, v_prev [, w_new])");
+        lbmpc_ctx* c = handle(prhs[1])->ctx;
         const int uq = (int)mxGetScalar(prhs[2]);
+        if (uq && nrhs < 8) mexErrMsgIdAndTxt("lbmpc:usage", "'step' with uq = 1 needs w_new");
         const double* dims = dbl(prhs[3]);  // [nx nu nc nS nW]
         const int nx = (int)dims[0], nu = (int)dims[1], nc = (int)dims[2], nS = (int)dims[3], nW = (int)dims[4];
         plhs[0] = mxCreateDoubleMatrix(nx, 1, mxREAL);
@@ -140,7 +176,8 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         for (int i = 1; i < nlhs && i <= 7; ++i) plhs[i] = outs[i - 1];
     } else if (cmd == "mc_run") {
         // R = lbmpc_mex('mc_run', h, sampler, cfg)  cfg: trials, steps, card_I0, seed, x0, acc_bound, distance_error, trial0
-        lbmpc_ctx* c = handle(prhs[1]);
+        need_args(nrhs, 4, "R = lbmpc_mex('mc_run', h, sampler, cfg)");
+        Handle* h = handle(prhs[1]);
         lbmpc_sampler smp; fill_sampler(prhs[2], &smp);
         const mxArray* s = prhs[3];
         lbmpc_mc_cfg cfg;
@@ -149,20 +186,33 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         cfg.steps = ifield(s, "steps"); cfg.card_I0 = ifield(s, "card_I0"); cfg.seed = (uint64_t)mxGetScalar(field(s, "seed"));
         cfg.x0 = dbl(field(s, "x0")); cfg.acc_bound = mxGetScalar(field(s, "acc_bound"));
         cfg.distance_error = mxGetScalar(field(s, "distance_error")); cfg.sampler_max_attempts = 1000;
-        const char* names[] = {"Infeasible_Index", "status", "alpha_K", "v_K"};
-        plhs[0] = mxCreateStructMatrix(1, 1, 4, names);
+        const mxArray* tt = mxGetField(s, 0, "traj_trials");   // optional: record State_RM / Control_EV of the first trials
+        cfg.traj_trials = tt ? (int32_t)mxGetScalar(tt) : 0;
+        if (cfg.traj_trials > cfg.trials) cfg.traj_trials = (int32_t)cfg.trials;
+        const char* names[] = {"Infeasible_Index", "status", "alpha_K", "v_K", "alpha_ini", "qp_iters", "State_RM", "Control_EV", "Alpha", "Nominal_RM_State"};
+        plhs[0] = mxCreateStructMatrix(1, 1, 10, names);
         mxArray* inf = mxCreateNumericMatrix(cfg.trials, 1, mxINT32_CLASS, mxREAL);
         mxArray* st = mxCreateNumericMatrix(cfg.trials, 1, mxINT32_CLASS, mxREAL);
         mxArray* aK = mxCreateDoubleMatrix(cfg.trials, 1, mxREAL);
         mxArray* vK = mxCreateDoubleMatrix(smp.nx, cfg.trials, mxREAL);
+        mxArray* a0 = mxCreateDoubleMatrix(cfg.trials, 1, mxREAL);
+        mxArray* it = mxCreateNumericMatrix(cfg.trials, 1, mxINT32_CLASS, mxREAL);
+        const size_t R = (size_t)cfg.traj_trials, K = (size_t)cfg.steps;
+        // trajectories as nx x (K+1) x R etc. flattened to 2-D (MATLAB reshapes): column block r is trial r
+        mxArray* tx = mxCreateDoubleMatrix(smp.nx, (K + 1) * R, mxREAL);
+        mxArray* tu = mxCreateDoubleMatrix(smp.nu, K * R, mxREAL);
+        mxArray* ta = mxCreateDoubleMatrix(K + 1, R, mxREAL);
+        mxArray* ts = mxCreateDoubleMatrix(smp.nx, K * R, mxREAL);
         lbmpc_mc_out out;
         std::memset(&out, 0, sizeof out);
         out.infeasible = (int32_t*)mxGetData(inf); out.status = (int32_t*)mxGetData(st);
         out.alpha_final = mxGetDoubles(aK); out.v_final = mxGetDoubles(vK);
-        int rc = lbmpc_mc_run(c, &smp, &cfg, &out);
+        out.alpha0 = mxGetDoubles(a0); out.qp_iters = (int32_t*)mxGetData(it);
+        if (R) { out.traj_x = mxGetDoubles(tx); out.traj_u = mxGetDoubles(tu); out.traj_alpha = mxGetDoubles(ta); out.traj_s0 = mxGetDoubles(ts); }
+        int rc = h->multi ? lbmpc_multi_mc_run(h->multi, &smp, &cfg, &out) : lbmpc_mc_run(h->ctx, &smp, &cfg, &out);
         if (rc < 0) fail("lbmpc:mc_run", rc);
-        mxSetField(plhs[0], 0, names[0], inf); mxSetField(plhs[0], 0, names[1], st);
-        mxSetField(plhs[0], 0, names[2], aK); mxSetField(plhs[0], 0, names[3], vK);
+        mxArray* vals[] = {inf, st, aK, vK, a0, it, tx, tu, ta, ts};
+        for (int i = 0; i < 10; ++i) mxSetField(plhs[0], 0, names[i], vals[i]);
     } else {
         mexErrMsgIdAndTxt("lbmpc:usage", "unknown command %s", cmdbuf);
     }

@@ -68,3 +68,53 @@ def test_context_runs_on_its_own_device():
     for k in ("infeasible", "status", "qp_iters"):
         np.testing.assert_array_equal(g[k], o[k], err_msg=k)
     ctx1.close()
+
+
+def test_block_shard_rule_matches_the_process_per_gpu_driver():
+    """the library's shard arithmetic (lbmpc_multi_mc_run, lbmpc_halfspace_max_multi) == lbmpc/dist.py's; shards are
+    contiguous, ordered, cover [0, total) and differ in size by at most one"""
+    from lbmpc import dist as ldist
+    for total in (0, 1, 7, 10000, 131072, 131073):
+        for world in (1, 2, 3, 8):
+            nxt = 0
+            sizes = []
+            for r in range(world):
+                first, count = core.block_shard(total, r, world)
+                assert (first, count) == ldist.block_shard(total, r, world)
+                assert first == nxt
+                nxt += count
+                sizes.append(count)
+            assert nxt == total and max(sizes) - min(sizes) <= 1
+    lib = _abi.load()
+    assert lib.lbmpc_block_shard(10, 3, 3, None, None) == _abi.ERR_ARG
+
+
+@pytest.mark.gpu
+def test_multi_gpu_entry_points_on_the_devices_present():
+    """lbmpc_multi_mc_run / lbmpc_halfspace_max_multi through the C ABI: with every device the box has (one on the
+    test box: unmeasured on N > 1 until a multi-GPU record exists), results bitwise those of the single-device entry
+    points; traj_trials and ragged shard sizes included"""
+    import torch
+    ndev = torch.cuda.device_count()
+    devs = list(range(ndev))
+    P = fixtures.params_dict()
+    smp = _abi.make_sampler(**fixtures.sampler_args(P))
+    core.init(0)
+    kw = dict(trials=1001, steps=9, card_I0=10, seed=13, x0=[-12.0, 5.0], acc_bound=2.0, distance_error=15.0, traj_trials=300)
+    ref = core.Context(P).mc_run(smp, **kw)
+    for dl in ([0], devs):
+        mc = core.MultiContext(P, dl)
+        got = mc.mc_run(smp, **kw)
+        for k in ref:
+            np.testing.assert_array_equal(ref[k], got[k], err_msg=f"{k} devices={dl}")
+        mc.close()
+    rng = np.random.default_rng(3)
+    S = rng.uniform(-0.3, 0.3, size=(7, 2, 5003))
+    want = core.halfspace_max(P["W_A"], S)
+    for dl in ([0], devs):
+        np.testing.assert_array_equal(core.halfspace_max_multi(P["W_A"], S, dl), want)
+    assert torch.cuda.current_device() == 0
+    with pytest.raises(core.LbmpcError):
+        core.MultiContext(P, [0, 0])
+    with pytest.raises(core.LbmpcError):
+        core.MultiContext(P, list(range(ndev + 1)))

@@ -84,10 +84,17 @@ def test_mrpiset_template_polytope(api, P):
     (an inner approximation of S(s, alpha) by sampled projections): every stored vertex lies inside the template, and
     the tightening h_S(F_Com) agrees with the stored hs within the epsilon-level slack (1 %)."""
     W = api.Polyhedron(A=P["W_A"], b=P["W_b"], V=P["W_V"])
-    Fs, info = api.MRPISet(P["Phi"], W, 0.01, return_info=True)
+    # the stored S was built from the reference's literal loop (MRPISet.m:27-63, mode 0): with its (s, alpha) every
+    # stored vertex lies inside the template
+    Fs, info = api.MRPISet(P["Phi"], W, 0.01, mode=_abi.MS_MAX_LITERAL, return_info=True)
     assert info["status"] == 0 and info["s"] >= 11
     viol = (Fs.A @ P["S_V"].T - Fs.b[:, None]).max()
     assert viol < 1e-3 * np.abs(P["S_V"]).max()
+    # the default (Rakovic form) is another epsilon-outer approximation of the same mRPI set: the two agree within
+    # the epsilon level (1 % of the set's size)
+    Fr, ir = api.MRPISet(P["Phi"], W, 0.01, return_info=True)
+    assert ir["status"] == 0
+    assert (Fr.A @ P["S_V"].T - Fr.b[:, None]).max() < 1e-2 * np.abs(P["S_V"]).max()
     Fc = P["F"] + P["G"] @ P["K"]
     from scipy.optimize import linprog
     hs = np.array([-linprog(-Fc[i], A_ub=Fs.A, b_ub=Fs.b, bounds=[(None, None)] * 2, method="highs").fun for i in range(4)])
@@ -126,3 +133,33 @@ def test_sample_polytope_vs_oracle(api, P):
     cr = x * y1 - x1 * y
     cen = np.array([((x + x1) * cr).sum(), ((y + y1) * cr).sum()]) / (3 * cr.sum())
     assert np.abs(out.mean(0) - cen).max() < 2e-3
+
+
+@pytest.mark.parametrize("system", ["3x3", "4x4"])
+def test_mrpiset_is_an_outer_template_on_generated_systems(api, system):
+    """MRPISet on the 3x3 / 4x4 systems: (s, alpha) in the Rakovic form (the default), and the returned template
+    polytope {x : d_j'x <= h_j} contains the set whose support the oracle evaluates: for 1e5 random directions d the
+    support of the template polytope's defining set, h_S(d) from the oracle, never exceeds what the template allows --
+    checked through its dual: every template row's h_j equals the oracle's h_S(d_j), and h_S is sublinear, so
+    h_S(d) <= sum_j lam_j h_j for any d = sum_j lam_j d_j, lam >= 0 (verified on random conic combinations)"""
+    from lbmpc import params
+    Pg = params.load(system)
+    nx = int(Pg["nx"])
+    W = api.Polyhedron(A=Pg["W_A"], b=Pg["W_b"], V=Pg["W_V"])
+    Fs, info = api.MRPISet(Pg["Phi"], W, 0.1, return_info=True)
+    assert info["status"] == 0 and 0.0 <= info["alpha"] < 1.0
+    s, alpha = info["s"], info["alpha"]
+    assert (s, alpha) == oracle_core.mrpi_s_alpha(Pg["Phi"], Pg["W_V"], Pg["W_A"], Pg["W_b"],
+                                                  api.reference_directions(nx, np.random.default_rng(0)).T, 0.1, mode=_abi.MS_RAKOVIC)[:2]
+    # every row is tight: b_j = h_S(d_j) (oracle)
+    np.testing.assert_allclose(Fs.b, oracle_core.support_batch(Pg["Phi"], Pg["W_V"], s, alpha, Fs.A.T, transpose=True), rtol=1e-9)
+    rng = np.random.default_rng(8)
+    n, k = 100000, 3
+    idx = rng.integers(0, Fs.A.shape[0], size=(n, k))
+    lam = rng.uniform(0.0, 1.0, size=(n, k))
+    D = np.einsum("nk,nkx->nx", lam, Fs.A[idx])
+    bound = (lam * Fs.b[idx]).sum(1)
+    hS = oracle_core.support_batch(Pg["Phi"], Pg["W_V"], s, alpha, D.T, transpose=True)
+    assert (hS <= bound * (1 + 1e-12) + 1e-15).all()
+    # epsilon-outer: alpha from the Rakovic loop satisfies the loop condition alpha <= eps / (eps + Ms)
+    assert alpha <= 0.1 / (0.1 + info["Ms"]) + 1e-15

@@ -1,0 +1,208 @@
+"""The MEX gateway (learning-based-mpc_amd/matlab/lbmpc_mex.cpp) compiled against the stand-in mex.h of
+tests/mex_stub/ and driven through its mexFunction: argument order of every command, plhs handling (nlhs = 0, fewer
+outputs than available), struct marshalling, handle life cycle, error mapping.  On the GPU the results are compared
+with the ctypes path on the same inputs.  MATLAB itself is absent from the build image: the real `mex` build stays
+unverified."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import fixtures
+from lbmpc import _abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "mex_stub", "libmexdrive.so")
+
+
+class Mex:
+    def __init__(self):
+        if not os.path.exists(SO):
+            import subprocess
+            subprocess.check_call(["make", "-C", os.path.join(HERE, "mex_stub"), "-s"])
+        L = self.L = C.CDLL(SO)
+        vp, sz = C.c_void_p, C.c_size_t
+        L.stub_double.argtypes, L.stub_double.restype = [sz, sz, _abi.c_double_p], vp
+        L.mxCreateString.argtypes, L.mxCreateString.restype = [C.c_char_p], vp
+        L.mxCreateNumericMatrix.argtypes, L.mxCreateNumericMatrix.restype = [sz, sz, C.c_int, C.c_int], vp
+        L.stub_struct.restype = vp
+        L.stub_add_field.argtypes = [vp, C.c_char_p, vp]
+        L.mxGetField.argtypes, L.mxGetField.restype = [vp, sz, C.c_char_p], vp
+        L.mxGetData.argtypes, L.mxGetData.restype = [vp], vp
+        L.mxGetM.argtypes, L.mxGetM.restype = [vp], sz
+        L.mxGetN.argtypes, L.mxGetN.restype = [vp], sz
+        L.mxGetClassID.argtypes, L.mxGetClassID.restype = [vp], C.c_int
+        L.mxDestroyArray.argtypes = [vp]
+        L.stub_call.argtypes = [C.c_int, C.POINTER(vp), C.c_int, C.POINTER(vp), C.c_char_p, C.c_int]
+        L.stub_last_warning.restype = C.c_char_p
+        L.stub_lock_count.restype = C.c_int
+
+    def to_mx(self, v):
+        L = self.L
+        if isinstance(v, str):
+            return L.mxCreateString(v.encode())
+        if isinstance(v, dict):
+            s = L.stub_struct()
+            for k, x in v.items():
+                L.stub_add_field(s, k.encode(), self.to_mx(x))
+            return s
+        if isinstance(v, Handle):
+            a = L.mxCreateNumericMatrix(1, 1, 15, 0)
+            C.cast(L.mxGetData(a), C.POINTER(C.c_uint64))[0] = v.value
+            return a
+        a = np.asfortranarray(np.atleast_2d(np.asarray(v, dtype=np.float64)))
+        if np.ndim(v) == 1:
+            a = np.asfortranarray(a.T)       # vectors go in as columns
+        return L.stub_double(a.shape[0], a.shape[1], a.ctypes.data_as(_abi.c_double_p))
+
+    def from_mx(self, p):
+        L = self.L
+        cls, m, n = L.mxGetClassID(p), L.mxGetM(p), L.mxGetN(p)
+        if cls == 6:
+            buf = C.cast(L.mxGetData(p), C.POINTER(C.c_double))
+            return np.array(buf[: m * n]).reshape((m, n), order="F")
+        if cls == 12:
+            buf = C.cast(L.mxGetData(p), C.POINTER(C.c_int32))
+            return np.array(buf[: m * n], dtype=np.int32).reshape((m, n), order="F")
+        if cls == 15:
+            return Handle(C.cast(L.mxGetData(p), C.POINTER(C.c_uint64))[0])
+        raise TypeError(cls)
+
+    def field(self, s, name):
+        p = self.L.mxGetField(s, 0, name.encode())
+        assert p, name
+        return self.from_mx(p)
+
+    def call(self, nlhs, *args, raw=False):
+        """lbmpc_mex(args...) with nlhs requested outputs -> list of outputs (at least one slot, as MATLAB gives)"""
+        L = self.L
+        prhs = (C.c_void_p * len(args))(*[self.to_mx(a) for a in args])
+        nout = max(nlhs, 1)
+        plhs = (C.c_void_p * 8)()
+        err = C.create_string_buffer(1024)
+        rc = L.stub_call(nlhs, plhs, len(args), prhs, err, 1024)
+        for p in prhs:
+            L.mxDestroyArray(p)
+        if rc:
+            raise RuntimeError(err.value.decode())
+        if raw:
+            return [plhs[i] for i in range(nout)]
+        return [self.from_mx(plhs[i]) for i in range(nout) if plhs[i]]
+
+
+class Handle:
+    def __init__(self, value):
+        self.value = int(value)
+
+
+@pytest.fixture(scope="module")
+def mex():
+    return Mex()
+
+
+def test_gateway_compiles_loads_and_maps_errors(mex):
+    """CPU part: the gateway builds against the stand-in API, usage errors come back as MATLAB error ids, and without
+    a GPU the first call fails with lbmpc:init (no fallback)"""
+    import torch
+    with pytest.raises(RuntimeError, match="lbmpc:usage"):
+        mex.call(0)
+    with pytest.raises(RuntimeError, match="lbmpc:usage"):
+        mex.call(0, np.zeros(3))
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="lbmpc:init.*(no HIP device|gfx950)"):
+            mex.call(1, "support_batch", np.eye(2), np.eye(2), 1, 0.0, np.eye(2), 1)
+
+
+def sampler_struct(P):
+    EVV, LVV = P["Xi_EV_V"], P["Xi_LV_V"]
+    return dict(nx=int(P["nx"]), nu=int(P["nu"]), EV_A=P["Xi_EV_H"][:, :-1], EV_b=P["Xi_EV_H"][:, -1], EV_lo=EVV.min(0),
+                EV_hi=EVV.max(0), LV_A=P["Xi_LV_H"][:, :-1], LV_b=P["Xi_LV_H"][:, -1], LV_lo=LVV.min(0), LV_hi=LVV.max(0),
+                B=np.reshape(P["B"], (int(P["nx"]), int(P["nu"]))), min_u_LV=np.ravel(P["min_u_LV"]), max_u_LV=np.ravel(P["max_u_LV"]))
+
+
+def params_struct(P):
+    nx, nu, N, nc = (int(P[k]) for k in ("nx", "nu", "N", "nc"))
+    nz = nx + N * nu
+    return dict(nx=nx, nu=nu, N=N, nc=nc, Nu=int(P["Nu"]), A=np.reshape(P["A"], (nx, nx)), B=np.reshape(P["B"], (nx, nu)),
+                K=np.reshape(P["K"], (nu, nx)), Phi=P["Phi"], Px=P["Px"], Pc=P["Pc"], F=np.reshape(P["F"], (nc, nx)),
+                G=np.reshape(P["G"], (nc, nu)), F_bar=np.reshape(P["F_bar"], (nc, nz)), Psi=P["Psi"], S_A=P["S_A"],
+                S_b=np.ravel(P["S_b"]), W_A=P["W_A"], W_b=np.ravel(P["W_b"]), hs=np.ravel(P["hs"]))
+
+
+@pytest.mark.gpu
+def test_gateway_commands_equal_the_ctypes_path(mex):
+    from lbmpc import core
+    core.init(0)
+    P = fixtures.params_dict()
+    smp = _abi.make_sampler(**fixtures.sampler_args(P))
+    rng = np.random.default_rng(1)
+    mex.call(0, "init", 0)
+    # support_batch / mrpi_s_alpha
+    D = rng.normal(size=(2, 300))
+    (h,) = mex.call(1, "support_batch", P["Phi"], P["W_V"], 7, 0.12, D, 1)
+    np.testing.assert_array_equal(h.ravel(), core.support_batch(P["Phi"], P["W_V"], 7, 0.12, D, transpose=True))
+    Dirs = np.hstack([np.eye(2), -np.eye(2)])
+    s, a, Ms = mex.call(3, "mrpi_s_alpha", P["Phi"], P["W_V"], P["W_A"], np.ravel(P["W_b"]), Dirs, 0.1, 2)
+    want = core.mrpi_s_alpha(P["Phi"], P["W_V"], P["W_A"], P["W_b"], Dirs, 0.1, mode=2)
+    assert (int(s[0, 0]), float(a[0, 0]), float(Ms[0, 0])) == want[:3]
+    (s_only,) = mex.call(0, "mrpi_s_alpha", P["Phi"], P["W_V"], P["W_A"], np.ravel(P["W_b"]), Dirs, 0.1, 2)   # nlhs = 0
+    assert int(s_only[0, 0]) == want[0]
+    # sample_sets / learn_set
+    S, m = mex.call(2, "sample_sets", sampler_struct(P), P["W_A"], 500, 2, 7)
+    S2, m2, _ = core.sample_information_sets(smp, P["W_A"], 500, 1, seed=2, set0=7)
+    np.testing.assert_array_equal(S, S2[0])
+    np.testing.assert_array_equal(m.ravel(), m2[0])
+    al, v, st = mex.call(3, "learn_set", P["W_A"], np.ravel(P["W_b"]), S)
+    a2, v2, _, st2 = core.homothety_lp(P["W_A"], P["W_b"], core.halfspace_max(P["W_A"], S))
+    assert float(al[0, 0]) == a2 and int(st[0, 0]) == st2
+    np.testing.assert_array_equal(v.ravel(), v2)
+    # create / step / mc_run / destroy
+    (hd,) = mex.call(1, "create", params_struct(P))
+    assert mex.L.stub_lock_count() == 1
+    ctx = core.Context(P)
+    dims = [2, 1, 4, P["S_A"].shape[0], 4]
+    x, vp, w = np.array([-8.0, 3.0]), np.array([0.01, -0.005]), np.array([0.05, 0.02])
+    outs = mex.call(8, "step", hd, 1, dims, x, 0.4, vp, w)
+    g = ctx.step(x, 0.4, vp, w, uq_update=True)
+    for o, k in zip(outs, ("s0", "u", "alpha", "v", "hk", "Sb_hat", "Wb_hat", "status")):
+        np.testing.assert_array_equal(np.ravel(o), np.ravel(g[k]), err_msg=k)
+    outs3 = mex.call(3, "step", hd, 0, dims, x, 1.0, np.zeros(2))        # nominal RMPC form: no w_new, 3 outputs
+    g0 = ctx.step(x, 1.0, np.zeros(2), None, uq_update=False)
+    np.testing.assert_array_equal(np.ravel(outs3[0]), g0["s0"])
+    np.testing.assert_array_equal(np.ravel(outs3[1]), np.ravel(g0["u"]))
+    with pytest.raises(RuntimeError, match="needs w_new"):
+        mex.call(1, "step", hd, 1, dims, x, 1.0, np.zeros(2))
+    mex.L.stub_clear_warning()
+    mex.call(1, "step", hd, 0, dims, np.array([40.0, 10.0]), 0.5, np.zeros(2))   # infeasible QP: warning, no error
+    assert b"lbmpc:status" in mex.L.stub_last_warning()
+    cfg = dict(trials=70, trial0=5, steps=12, card_I0=10, seed=3, x0=np.array([-12.0, 5.0]), acc_bound=2.0,
+               distance_error=15.0, traj_trials=4)
+    (R,) = mex.call(1, "mc_run", hd, sampler_struct(P), cfg, raw=True)
+    ref = ctx.mc_run(smp, trials=70, trial0=5, steps=12, card_I0=10, seed=3, x0=[-12.0, 5.0], acc_bound=2.0,
+                     distance_error=15.0, traj_trials=4)
+    np.testing.assert_array_equal(mex.field(R, "Infeasible_Index").ravel(), ref["infeasible"])
+    np.testing.assert_array_equal(mex.field(R, "qp_iters").ravel(), ref["qp_iters"])
+    np.testing.assert_array_equal(mex.field(R, "alpha_K").ravel(), ref["alpha_final"])
+    np.testing.assert_array_equal(mex.field(R, "alpha_ini").ravel(), ref["alpha0"])
+    np.testing.assert_array_equal(mex.field(R, "v_K").T, ref["v_final"])
+    np.testing.assert_array_equal(mex.field(R, "State_RM").T.reshape(4, 13, 2), ref["traj_x"])
+    np.testing.assert_array_equal(mex.field(R, "Control_EV").T.reshape(4, 12, 1), ref["traj_u"])
+    np.testing.assert_array_equal(mex.field(R, "Alpha").T, ref["traj_alpha"])
+    # a handle created with ngpu = 1 explicitly, and one that asks for more GPUs than the box has
+    (hd2,) = mex.call(1, "create", params_struct(P), 1)
+    (R2,) = mex.call(1, "mc_run", hd2, sampler_struct(P), cfg, raw=True)
+    np.testing.assert_array_equal(mex.field(R2, "qp_iters").ravel(), ref["qp_iters"])
+    import torch
+    with pytest.raises(RuntimeError, match="lbmpc:create"):
+        mex.call(1, "create", params_struct(P), torch.cuda.device_count() + 1)
+    mex.call(0, "destroy", hd2)
+    mex.call(0, "destroy", hd)
+    assert mex.L.stub_lock_count() == 0
+    with pytest.raises(RuntimeError, match="lbmpc:handle"):
+        mex.call(0, "destroy", hd)                       # stale handle
+    with pytest.raises(RuntimeError, match="lbmpc:field"):
+        mex.call(1, "create", dict(nx=2))                # missing fields
+    with pytest.raises(RuntimeError, match="unknown command"):
+        mex.call(0, "frobnicate")
+    ctx.close()
