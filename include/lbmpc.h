@@ -180,11 +180,14 @@ int lbmpc_sample_polytope(const double* XA, const double* Xb, int nr, int nx, co
  * (alpha = 1-beta, v = y/beta), one problem per column of m (nW x batch).
  * Replaces Functions_general/InitialSetComputation.m:69-83,:85-99 (LP, LP_opt) and
  * Functions_general/UQRobustMPC.m:124-139 (LPforUQ, with m = max(b_hat_prev, WA w_new)).
- * alpha is unique; y is not (SURVEY.md hard part 1): tiebreak LBMPC_TIE_CENTER returns the
- * midpoint of each coordinate's optimal interval (requires an axis-aligned box W, which is what
- * every reference configuration uses; otherwise LBMPC_ERR_UNSUPPORTED).
- * active_mask (batch x uint32, may be NULL): bit k set if axis k attains alpha (k < nx).
- * status (batch ints, may be NULL): LBMPC_ST_LP_INFEASIBLE where some m_j > Wb_j. */
+ * alpha is unique; y is not (SURVEY.md hard part 1): tiebreak LBMPC_TIE_CENTER returns, for an axis-aligned box W
+ * (every reference configuration), the midpoint of each coordinate's optimal interval (closed form), and for any other
+ * bounded polytope W (nx+1 <= nW <= 16) the mean of the feasible basic solutions of the optimal face (vertex
+ * enumeration, one lane per LP: C(2nW+2, nx+1) small solves, meant for set learning, not for the closed loop, whose
+ * controllers take box priors only); the two coincide on a box.
+ * active_mask (batch x uint32, may be NULL): box W: bit k set if axis k attains alpha (k < nx); general W: bit j set if
+ * row j of W binds on either side.
+ * status (batch ints, may be NULL): LBMPC_ST_LP_INFEASIBLE where the LP has no feasible point (some m_j > Wb_j). */
 #define LBMPC_TIE_CENTER 1
 int lbmpc_homothety_lp(const double* WA, const double* Wb, int nW, int nx, const double* m,
                        int64_t batch, int tiebreak, double* alpha, double* v, uint32_t* active_mask,

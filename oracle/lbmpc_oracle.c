@@ -419,6 +419,67 @@ int orc_homothety_box(const int* pr, const int* qr, const double* ic, const doub
     return 0;
 }
 
+/* GENERAL polytope W (InitialSetComputation.m:69-99 accepts any W): beta* by the vertex enumeration above, then the
+ * canonical y of LBMPC_TIE_CENTER for a general W: the mean of the feasible basic solutions of the optimal face
+ * Y* = {y : W_A y <= beta* W_b, -W_A y <= (1-beta*) W_b - m} over all nx-subsets of its 2 nW rows (subsets with a
+ * singular matrix skipped; subsets in lexicographic order).  A convex combination of vertices of Y*, hence optimal;
+ * for a box it is the midpoint of every coordinate's optimal interval, the rule of the closed form below.
+ * active_mask: bit j set when row j of W binds on either side (|slack| <= 1e-9). */
+int orc_homothety_general(const double* WA, const double* Wb, int nW, int nx, const double* m,
+                          double* alpha, double* v, uint32_t* active_mask) {
+    double y1[LBMPC_MAX_NX];
+    int st = orc_homothety_lp_enum(WA, Wb, nW, nx, m, alpha, v, y1);
+    if (active_mask) *active_mask = 0;
+    if (st) return st;
+    const double beta = 1.0 - *alpha;
+    int nr = 2 * nW;
+    double R[2 * LBMPC_MAX_NW * LBMPC_MAX_NX], rhs[2 * LBMPC_MAX_NW];
+    for (int j = 0; j < nW; ++j) {
+        for (int k = 0; k < nx; ++k) { R[j * nx + k] = CM(WA, nW, j, k); R[(nW + j) * nx + k] = -CM(WA, nW, j, k); }
+        rhs[j] = beta * Wb[j];
+        rhs[nW + j] = (Wb[j] - m[j]) - beta * Wb[j];
+    }
+    int idx[LBMPC_MAX_NX];
+    for (int k = 0; k < nx; ++k) idx[k] = k;
+    double sum[LBMPC_MAX_NX];
+    for (int k = 0; k < nx; ++k) sum[k] = 0.0;
+    int count = 0;
+    for (;;) {
+        double M[LBMPC_MAX_NX * LBMPC_MAX_NX], x[LBMPC_MAX_NX];
+        for (int a = 0; a < nx; ++a) {
+            for (int k = 0; k < nx; ++k) M[a * nx + k] = R[idx[a] * nx + k];
+            x[a] = rhs[idx[a]];
+        }
+        if (solve_dense(nx, M, x)) {
+            int ok = 1;
+            for (int r = 0; r < nr && ok; ++r) {
+                double acc = 0.0;
+                for (int k = 0; k < nx; ++k) acc += R[r * nx + k] * x[k];
+                if (acc > rhs[r] + 1e-11) ok = 0;
+            }
+            if (ok) { for (int k = 0; k < nx; ++k) sum[k] += x[k]; count++; }
+        }
+        int p = nx - 1;
+        while (p >= 0 && idx[p] == nr - nx + p) --p;
+        if (p < 0) break;
+        ++idx[p];
+        for (int k = p + 1; k < nx; ++k) idx[k] = idx[k - 1] + 1;
+    }
+    double y[LBMPC_MAX_NX];
+    for (int k = 0; k < nx; ++k) y[k] = count > 0 ? sum[k] / (double)count : y1[k];
+    for (int k = 0; k < nx; ++k) v[k] = beta > 0.0 ? y[k] / beta : 0.0;
+    if (active_mask) {
+        uint32_t mask = 0;
+        for (int j = 0; j < nW; ++j) {
+            double acc = 0.0;
+            for (int k = 0; k < nx; ++k) acc += R[j * nx + k] * y[k];
+            if (fabs(rhs[j] - acc) <= 1e-9 || fabs(rhs[nW + j] + acc) <= 1e-9) mask |= 1u << j;
+        }
+        *active_mask = mask;
+    }
+    return 0;
+}
+
 int orc_homothety_lp(const double* WA, const double* Wb, int nW, int nx, const double* m,
                      int64_t batch, int tiebreak, double* alpha, double* v, uint32_t* active_mask,
                      int* status) {
@@ -426,6 +487,16 @@ int orc_homothety_lp(const double* WA, const double* Wb, int nW, int nx, const d
     double ic[LBMPC_MAX_NW];
     if (tiebreak != LBMPC_TIE_CENTER) return LBMPC_ERR_ARG;
     int rc = orc_box_structure(WA, nW, nx, pr, qr, ic);
+    if (rc == LBMPC_ERR_UNSUPPORTED) { /* not an axis-aligned box: the general solver */
+        if (nW > LBMPC_MAX_NW || nx > LBMPC_MAX_NX) return LBMPC_ERR_DIM;
+        for (int64_t b = 0; b < batch; ++b) {
+            uint32_t mask;
+            int st = orc_homothety_general(WA, Wb, nW, nx, m + (size_t)b * nW, alpha + b, v + (size_t)b * nx, &mask);
+            if (active_mask) active_mask[b] = mask;
+            if (status) status[b] = st;
+        }
+        return 0;
+    }
     if (rc) return rc;
     for (int64_t b = 0; b < batch; ++b) {
         uint32_t mask;

@@ -79,11 +79,56 @@ def test_halfspace_max_errors(core, P):
         core.halfspace_max(np.zeros((17, 2)), np.zeros((2, 4)))       # nW beyond limit
     with pytest.raises(core.LbmpcError):
         core.halfspace_max(np.zeros((4, 5)), np.zeros((5, 4)))        # nx beyond limit
+    # a W that is not a bounded polytope (four copies of one halfspace): no basic solution exists, reported as status
+    a, v, mask, st = core.homothety_lp(np.ones((4, 2)), np.ones(4), np.zeros(4))
+    assert st == _abi.ST_LP_INFEASIBLE and a == 1.0
     with pytest.raises(core.LbmpcError):
-        core.homothety_lp(np.ones((4, 2)), np.ones(4), np.zeros(4))   # W not an axis-aligned box
+        core.homothety_lp(np.ones((2, 2)), np.ones(2), np.zeros(2))   # fewer than nx + 1 rows
     # a sample outside the prior W: LP infeasible, reported (the reference returns IPOPT garbage)
     a, v, mask, st = core.homothety_lp(P["W_A"], P["W_b"], P["W_b"] * np.array([1.0, 1.5, 1.0, 1.0]))
     assert st == _abi.ST_LP_INFEASIBLE and a == 1.0
+
+
+@pytest.mark.parametrize("case", ["W_true", "3d", "4d"])
+def test_homothety_lp_general_polytope(core, P, case):
+    """prior W that is not an axis-aligned box (InitialSetComputation.m:69-99 takes any W): vertex-enumeration LP on
+    the device == the oracle's, bit for bit (alpha, v, binding rows, status); alpha also against HiGHS; the returned v
+    lies on the optimal face"""
+    from scipy.optimize import linprog
+    rng = np.random.default_rng(42)
+    if case == "W_true":
+        H = P["W_true_H"]
+        WA, Wb = H[:, :-1], H[:, -1]
+    else:
+        nx = 3 if case == "3d" else 4
+        nW = nx + 5
+        WA = rng.normal(size=(nW, nx))
+        WA = np.vstack([WA, -WA.sum(0, keepdims=True)])     # rows that positively span R^nx: bounded
+        WA /= np.linalg.norm(WA, axis=1, keepdims=True)
+        Wb = rng.uniform(0.5, 1.5, WA.shape[0])
+    nW, nx = WA.shape
+    B = 37
+    # sample clouds inside W (scaled so that 0 < alpha < 1), one far outside (infeasible)
+    M = np.zeros((B, nW))
+    for b in range(B):
+        X = rng.normal(size=(nx, 40)) + 0.5 * rng.normal(size=(nx, 1))     # an off-centre cloud
+        X *= rng.uniform(0.1, 0.9) / np.maximum((WA @ X) / Wb[:, None], 1e-9).max()   # gauge of W: inside
+        M[b] = (WA @ X).max(1)
+    M[-1] = Wb * 1.5
+    a, v, mask, st = core.homothety_lp(WA, Wb, M)
+    a2, v2, mask2, st2 = oracle_core.homothety_lp(WA, Wb, M)
+    np.testing.assert_array_equal(st, st2)
+    np.testing.assert_array_equal(a, a2)
+    np.testing.assert_array_equal(v, v2)
+    np.testing.assert_array_equal(mask, mask2)
+    assert st[-1] == _abi.ST_LP_INFEASIBLE and (st[:-1] == 0).all()
+    c = np.zeros(nx + 1); c[0] = -1
+    A = np.vstack([np.hstack([-Wb[:, None], WA]), np.hstack([Wb[:, None], -WA])])
+    for b in range(0, B - 1, 6):
+        r = linprog(c, A_ub=A, b_ub=np.concatenate([np.zeros(nW), Wb - M[b]]), bounds=[(0, 1)] + [(None, None)] * nx, method="highs")
+        assert abs((1 - r.x[0]) - a[b]) < 1e-9
+        x = np.concatenate([[1 - a[b]], (1 - a[b]) * v[b]])
+        assert (A @ x <= np.concatenate([np.zeros(nW), Wb - M[b]]) + 1e-9).all()
 
 
 def test_sampler_stream_bit_exact(core, P, smp):
