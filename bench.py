@@ -192,10 +192,25 @@ def main():
 
         P1 = params.load(os.path.join(ROOT, "tests", "golden", "params_2x2.npz"))
         qp_active["C1_2x2_case3"] = qp_leg("C1", P1, [-12.0, 5.0], 65536, 50, 100, 1)
+        # C3 as written: Case_5...:25-47 -- learn a set, S_hat_ini, hs_UQMPC, F_N_Hat (ComputeFeasibleRegion on the
+        # polytope-support LP kernel), x_RM_0 near the boundary of F_N_Hat
+        from lbmpc import api
         P3 = params.load("3x3")
-        x03 = np.ravel(P3["x0_case5"]) if "x0_case5" in P3 else np.array([-12.0, 5.0, 0.0])
+        S3 = api.Polyhedron(A=P3["S_A"], b=P3["S_b"])
+        t_fr = time.perf_counter()
+        fr = api.ComputeFeasibleRegion(dict(S=S3, S_true=S3, S_hat_opt=S3, F=P3["F"], G=P3["G"], K=P3["K"], F_bar=P3["F_bar"],
+                                            Psi=P3["Psi"], nc=int(P3["nc"]), nx=3, nu=int(P3["nu"]), N=int(P3["N"]), Ps=None))
+        _, m3, _ = core.sample_information_sets(params.sampler(P3, oriented=True), P3["W_A"], 10, 1, seed=5, set0=0, want_samples=False)
+        a3, v3, _, _ = core.homothety_lp(P3["W_A"], P3["W_b"], m3[0])
+        S_hat3 = a3 * S3 + (1 - a3) * (np.linalg.inv(np.eye(3) - P3["Phi"]) @ v3)
+        _, F_N_Hat = fr.ComFeasibleRegion_UQMPC(S_hat3, fr.ComFeasibleRegion_UQMPC_Hs_ini(S_hat3))
+        x03 = api.case_5_initial_state(F_N_Hat.V)
+        t_fr = time.perf_counter() - t_fr
         qp_active["C3_3x3_case5"] = qp_leg("C3", P3, x03, 10000, 20, 10, 5)
         qp_active["C3_3x3_case5"]["x_RM_0"] = [float(t) for t in x03]
+        qp_active["C3_3x3_case5"]["feasible_region_s"] = t_fr
+        qp_active["C3_3x3_case5"]["note"] = ("x_RM_0 from the coordinate extremes of F_N_Hat = F_Ns (+) S_hat_ini (Case_5...:45-47), "
+                                             f"{F_N_Hat.A.shape[0]} template directions through lbmpc_polytope_support; host time incl. copies")
         qp_active["C4_4x4_transient"] = qp_leg("C4t", P, x0, args.trials, 32, args.card_i0, 4)
         qp_active["C4_4x4_transient"]["note"] = ("the first 32 steps of the C4 launch (pre-pass + transient kernel): every QP of "
                                                  "C4 is solved here; the remaining steps pass the ellipsoid test")

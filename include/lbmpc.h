@@ -47,6 +47,7 @@ extern "C" {
 #define LBMPC_ST_LP_INFEASIBLE 2 /* a sample lies outside the prior W (beta < 0 needed)    */
 #define LBMPC_ST_ITER_CAP 3      /* active-set iteration cap reached                       */
 #define LBMPC_ST_SAMPLER_CAP 4   /* rejection sampler hit max attempts                     */
+#define LBMPC_ST_LP_UNBOUNDED 5  /* support LP unbounded in the asked direction            */
 
 /* compiled limits */
 #define LBMPC_MAX_NX 4
@@ -282,6 +283,21 @@ typedef struct lbmpc_mc_out { /* device or host pointers depending on the entry 
 int lbmpc_mc_run(lbmpc_ctx* ctx, const lbmpc_sampler* smp, const lbmpc_mc_cfg* cfg, lbmpc_mc_out* out);
 int lbmpc_mc_run_dev(lbmpc_ctx* ctx, const lbmpc_sampler* smp, const lbmpc_mc_cfg* cfg,
                      lbmpc_mc_out* out_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Feasible-region geometry
+ * ---------------------------------------------------------------------------------------- */
+
+/* h_out[i + nd*s] = max { C[:,i]' z : A z <= b[:,s] }: the support function of a polytope in H-rep by an exact LP, for
+ * nd directions (C: n x nd) and nb right-hand sides (b: m x nb, every entry > 0: z = 0 strictly feasible); A: m x n.
+ * z_out (n x nd x nb, may be NULL): a maximiser; status_out (nd x nb, may be NULL): 0, LBMPC_ST_LP_UNBOUNDED or
+ * LBMPC_ST_ITER_CAP.  One LP per lane (primal active-set method with Bland's rule).
+ * Replaces the IPOPT LPs of Functions_general/ComputeFeasibleRegion.m: Com_hs / Com_hs_ini (:447-503, A = S_A),
+ * Com_z (:505-519, the nu_s search of :66-116), and the sampled projections of :153-171, :395-413 (with A the rows
+ * F_bar Psi^i, i = 0..nu, and C = [d; 0] it returns the exact support of the nominal feasible region F_Ns, so that
+ * h_{F_N}(d) = h_{F_Ns}(d) + h_{S_hat}(d) needs no hull of 5000 projected samples). */
+int lbmpc_polytope_support(const double* A, int m, int n, const double* b, int64_t nb, const double* C, int64_t nd,
+                           double* h_out, double* z_out, int* status_out);
 
 /* ------------------------------------------------------------------------------------------
  * One node, several GPUs, inside one process (the MATLAB drop-in is a single process)

@@ -16,7 +16,7 @@ c_uint32_p = C.POINTER(C.c_uint32)
 
 MAX_NX, MAX_NZ, MAX_NC, MAX_NW, MAX_NXI, MAX_NV, MAX_S = 4, 16, 16, 16, 16, 1024, 64
 ERR_ARG, ERR_DIM, ERR_HIP, ERR_UNSUPPORTED, ERR_NODEVICE = -1, -2, -3, -4, -5
-ST_OK, ST_QP_INFEASIBLE, ST_LP_INFEASIBLE, ST_ITER_CAP, ST_SAMPLER_CAP = 0, 1, 2, 3, 4
+ST_OK, ST_QP_INFEASIBLE, ST_LP_INFEASIBLE, ST_ITER_CAP, ST_SAMPLER_CAP, ST_LP_UNBOUNDED = 0, 1, 2, 3, 4, 5
 MS_MAX_LITERAL, MS_SUM_LITERAL, MS_RAKOVIC = 0, 1, 2
 TIE_CENTER = 1
 DEVICE_CURRENT = -1
@@ -142,6 +142,7 @@ def declare(lib, prefix):
         "sample_information_sets": [C.POINTER(Sampler), dp, ci, i64, i64, u64, u64, ci, dp, dp, ip],
         "homothety_lp": [dp, dp, ci, ci, dp, i64, ci, dp, dp, up, ip],
         "sample_polytope": [dp, dp, ci, ci, dp, dp, i64, u64, u64, C.c_uint32, ci, ci, dp, ip],
+        "polytope_support": [dp, ci, ci, dp, i64, dp, i64, dp, dp, ip],
         "uqmpc_create": [C.POINTER(Params), C.POINTER(vp)],
         "uqmpc_step": [vp, i64, ci, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, ip, ip, ip, ip],
         "mc_run": [vp, C.POINTER(Sampler), C.POINTER(McCfg), C.POINTER(McOut)],

@@ -251,3 +251,143 @@ def monte_carlo(opts_UQMPC, opts_Car, N_pre_sam, N_MC, K_N, x_RM_0, acc_bound, d
                 State_RM=np.transpose(o["traj_x"], (0, 2, 1)), Control_EV=np.transpose(o["traj_u"], (0, 2, 1)),
                 Nominal_RM_State=np.transpose(o["traj_s0"], (0, 2, 1)), Alpha=o["traj_alpha"],
                 W_Hat_Vol=o["traj_alpha"] ** nx * volW)
+
+
+def template_directions(nx, n=None, seed=0):
+    """unit directions of an H-rep template in R^nx: +-I first (so that coordinate extremes are exact), then evenly
+    spaced angles (nx = 2) or seeded random unit vectors"""
+    E = np.vstack([np.eye(nx), -np.eye(nx)])
+    if nx == 1:
+        return E
+    if nx == 2:
+        n = 360 if n is None else n
+        th = 2 * np.pi * (np.arange(n) + 0.5) / n
+        return np.vstack([E, np.column_stack([np.cos(th), np.sin(th)])])
+    n = {3: 795, 4: 1644}.get(nx, 1644) if n is None else n
+    D = np.random.default_rng(seed).normal(size=(n, nx))
+    return np.vstack([E, D / np.linalg.norm(D, axis=1, keepdims=True)])
+
+
+class ComputeFeasibleRegion:
+    """Functions_general/ComputeFeasibleRegion.m with the same constructor fields (S, S_true, S_hat_opt, F, G, K, F_bar,
+    Psi, nc, nx, nu, N, Ps, num_half_space_S) and methods.  Every LP the reference hands to IPOPT (Com_hs, Com_z,
+    Com_hs_ini) is one call of lbmpc_polytope_support; the feasible region F_N = F_Ns (+) S is returned as the H-rep
+    template polytope {x : d_j'x <= h_{F_Ns}(d_j) + h_S(d_j)} of its EXACT support instead of the hull of 5000 sampled
+    YALMIP projections (:153-203) -- `.V` holds one boundary point per template direction (maximiser of F_Ns plus
+    maximiser of S), so callers that take min / max over `.V` columns (Case_5...:45-47) get the exact coordinate
+    extremes."""
+
+    def __init__(self, parameters, directions=None, backend=None):
+        p = parameters
+        self.S, self.S_true, self.S_hat_opt = p["S"], p.get("S_true"), p.get("S_hat_opt")
+        self.nc, self.nx, self.nu, self.N = (int(np.ravel(p[k])[0]) for k in ("nc", "nx", "nu", "N"))
+        nz = self.nx + self.N * self.nu
+        self.F = np.asarray(p["F"], dtype=np.float64).reshape(self.nc, self.nx)
+        self.G = np.asarray(p["G"], dtype=np.float64).reshape(self.nc, self.nu)
+        self.K = np.asarray(p["K"], dtype=np.float64).reshape(self.nu, self.nx)
+        self.F_bar = np.asarray(p["F_bar"], dtype=np.float64).reshape(self.nc, nz)
+        self.Psi = np.asarray(p["Psi"], dtype=np.float64)
+        self.Ps = p.get("Ps")
+        self.F_Com = self.F + self.G @ self.K
+        self.D = template_directions(self.nx) if directions is None else np.asarray(directions, dtype=np.float64)
+        self._lp = core.polytope_support if backend is None else backend   # tests pass the oracle's twin
+
+    # ---- the LPs (ComputeFeasibleRegion.m:447-519) ----
+    def _hs(self, S, rows):
+        h, st = self._lp(S.A, S.b, np.asarray(rows, dtype=np.float64).T)
+        if st.max() != 0:
+            raise RuntimeError(f"support LP over the tube set failed with status {int(st.max())}")
+        return h
+
+    def _H(self, Nu):
+        M, rows = self.F_bar.copy(), []
+        for _ in range(Nu + 1):
+            rows.append(M)
+            M = M @ self.Psi
+        return np.vstack(rows)
+
+    def ComNu_RMPC(self, hs, literal=False, max_Nu=100):
+        """smallest Nu >= N with max {F_bar Psi^(Nu+1) z : z in Omega} <= 1 - hs  (:66-116).
+        literal=False: Omega = {F_bar Psi^i z <= 1 - hs, i = 0..Nu}, the set the condition is about.
+        literal=True: the reference's LP as written (Com_z gets M_before = F_bar Psi^Nu only, :76,:514).  In exact
+        arithmetic that LP does not depend on Nu at all (substitute eta = Phi^(Nu-N) xi), so its exit test either
+        holds at Nu = N or never; the Nu = 19 stored in parameters_2x2.mat comes from IPOPT's absolute tolerances on
+        rows that shrink like rho(Phi)^Nu and cannot be reproduced by an exact solver.  Since every row beyond the
+        exact nu_s is redundant, Omega(1 - hs, 19) = Omega(1 - hs, nu_s): the stored value is valid, only larger."""
+        hs = np.ravel(hs)
+        Nu = self.N
+        while Nu < max_Nu:
+            M = self.F_bar @ np.linalg.matrix_power(self.Psi, Nu + 1)
+            A = self.F_bar @ np.linalg.matrix_power(self.Psi, Nu) if literal else self._H(Nu)
+            b = (1 - hs) if literal else np.tile(1 - hs, Nu + 1)
+            goal, st = self._lp(A, b, M.T)
+            if st.max() == 0 and np.all(goal <= 1 - hs):
+                break
+            Nu += 1
+        return Nu
+
+    def Com_Nuk(self, hk, hs, Nu):
+        """:521-535 (Alg. 1) with the intended exponent in the loop (the reference's `obj.Nu_k` is a typo that would
+        raise as soon as the loop body runs)"""
+        hk, hs = np.ravel(hk), np.ravel(hs)
+        zeta = np.max((1 - hk) / (1 - hs))
+        Ps = np.ones((self.Psi.shape[0],) * 2) if self.Ps is None else np.asarray(self.Ps, dtype=np.float64)
+        Pi = np.linalg.pinv(Ps)
+        Nu_k = Nu
+        for _ in range(200):
+            Pk = np.linalg.matrix_power(self.Psi, Nu_k + 1)
+            vec = [self.F_bar[i] @ Pk @ Pi @ Pk.T @ self.F_bar[i] - (1 - hk[i]) / zeta ** 2 for i in range(self.nc)]
+            if max(vec) <= 0:
+                break
+            Nu_k += 1
+        return Nu_k
+
+    def _region(self, S, h, Nu):
+        """F_Ns = proj_s Omega(1 - h, Nu) and F_N = F_Ns (+) S as template polytopes over self.D"""
+        nz = self.Psi.shape[0]
+        Cd = np.zeros((nz, self.D.shape[0]))
+        Cd[: self.nx] = self.D.T
+        hF, st, z = self._lp(self._H(Nu), np.tile(1 - np.ravel(h), Nu + 1), Cd, want_z=True)
+        hS, st2, e = self._lp(S.A, S.b, self.D.T, want_z=True)
+        if st.max() != 0 or st2.max() != 0:
+            raise RuntimeError(f"feasible-region LP failed with status {int(max(st.max(), st2.max()))}")
+        F_Ns = Polyhedron(A=self.D, b=hF, V=z[:, : self.nx])
+        F_N = Polyhedron(A=self.D, b=hF + hS, V=z[:, : self.nx] + e)
+        return F_Ns, F_N
+
+    def ComFeasibleRegion_RMPC(self):
+        """[F_N, hs, Nu] = ComFeasibleRegion_RMPC()  (:118-203)"""
+        hs = self._hs(self.S, self.F_Com)
+        Nu = self.ComNu_RMPC(hs)
+        return self._region(self.S, hs, Nu)[1], hs.reshape(-1, 1), Nu
+
+    def ComFeasibleRegion_True(self):
+        """[F_N, hs_true] = ComFeasibleRegion_True()  (:257-327)"""
+        hs = self._hs(self.S_true, self.F_Com)
+        return self._region(self.S_true, hs, self.ComNu_RMPC(hs))[1], hs.reshape(-1, 1)
+
+    def ComFeasibleRegion_UQOPT(self):
+        """[F_N_hat_opt, hs_hat_opt] = ComFeasibleRegion_UQOPT()  (:329-378)"""
+        hs = self._hs(self.S_hat_opt, self.F_Com)
+        return self._region(self.S_hat_opt, hs, self.ComNu_RMPC(hs))[1], hs.reshape(-1, 1)
+
+    def ComFeasibleRegion_UQMPC(self, S_hat, h_k):
+        """[F_Ns, F_N] = ComFeasibleRegion_UQMPC(S_hat, h_k)  (:380-435): rows i = 0..Nu_k with 1 - h_k"""
+        hs = self._hs(self.S, self.F_Com)
+        Nu_k = self.Com_Nuk(h_k, hs, self.ComNu_RMPC(hs))
+        return self._region(S_hat, h_k, Nu_k)
+
+    def ComFeasibleRegion_UQMPC_Hs_ini(self, S_hat_ini):
+        """hs_ini = ComFeasibleRegion_UQMPC_Hs_ini(S_hat_ini)  (:437-445)"""
+        return self._hs(S_hat_ini, self.F_Com).reshape(-1, 1)
+
+
+def case_5_initial_state(V):
+    """x_RM_0 of Case_5...:45-47 from the vertices of F_N_Hat: first coordinate 0.1 inside the lower extreme, second
+    0.3 inside the upper extreme, the rest 0"""
+    V = np.asarray(V, dtype=np.float64)
+    x = np.zeros(V.shape[1])
+    x[0] = V[:, 0].min() + 0.1
+    if V.shape[1] >= 2:
+        x[1] = V[:, 1].max() - 0.3
+    return x

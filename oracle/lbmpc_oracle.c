@@ -979,3 +979,121 @@ int orc_mc_run_omp(orc_ctx* c, const lbmpc_sampler* smp, const lbmpc_mc_cfg* cfg
     for (int64_t t = 0; t < cfg->trials; ++t) mc_trial(c, smp, cfg, out, t);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Support function of a polytope in H-rep by an exact LP: the LPs of
+ * Functions_general/ComputeFeasibleRegion.m -- Com_hs (:447-503: max F_com e s.t. S_A e <= S_b),
+ * Com_z (:505-519: max M_i z s.t. M_before z <= 1 - hs, the nu_s search :66-116) and the support of the
+ * nominal feasible region F_Ns = proj_s {z : F_bar Psi^i z <= 1 - h, i = 0..nu} (the set the 5000
+ * YALMIP projections of :153-171 sample) -- which the reference hands to IPOPT.
+ * Primal active-set method from the interior point z = 0 (needs b > 0): move along the projection p of c
+ * onto the null space of the working rows until a row blocks (ratio test, lowest row on ties), add it;
+ * when p vanishes the multipliers of c = A_W' lam decide: all >= 0 optimal, else drop the LOWEST ROW with a
+ * negative multiplier (Bland).  Rows are normalised to unit 2-norm by the caller.  Dense Cholesky of
+ * A_W A_W' (k <= n <= 16) from scratch at every iteration.
+ * ---------------------------------------------------------------------------------------- */
+#define LP_MAX_ITERS 400
+
+
+static int lp_support_one(const double* A /* m x n row-major, unit rows */, const double* b, int m, int n,
+                          const double* c, double* value, double* zout, int* iters_out) {
+    double z[LBMPC_MAX_NZ], p[LBMPC_MAX_NZ], lam[LBMPC_MAX_NZ], L[LBMPC_MAX_NZ][LBMPC_MAX_NZ];
+    int W[LBMPC_MAX_NZ], k = 0, iters = 0, status = 0;
+    double cn = 0.0;
+    for (int i = 0; i < n; ++i) { z[i] = 0.0; if (fabs(c[i]) > cn) cn = fabs(c[i]); }
+    if (cn == 0.0) { *value = 0.0; if (zout) for (int i = 0; i < n; ++i) zout[i] = 0.0; if (iters_out) *iters_out = 0; return 0; }
+    for (;;) {
+        if (++iters > LP_MAX_ITERS) { status = LBMPC_ST_ITER_CAP; break; }
+        /* lam = (A_W A_W')^-1 A_W c ; p = c - A_W' lam */
+        for (int a = 0; a < k; ++a) {
+            for (int bq = 0; bq <= a; ++bq) {
+                double acc = 0.0;
+                for (int i = 0; i < n; ++i) acc = fma(A[(size_t)W[a] * n + i], A[(size_t)W[bq] * n + i], acc);
+                for (int q = 0; q < bq; ++q) acc = fma(-L[a][q], L[bq][q], acc);
+                if (a == bq) L[a][a] = sqrt(acc > 0.0 ? acc : 0.0);
+                else L[a][bq] = acc / L[bq][bq];
+            }
+            double r = 0.0;
+            for (int i = 0; i < n; ++i) r = fma(A[(size_t)W[a] * n + i], c[i], r);
+            lam[a] = r;
+        }
+        for (int a = 0; a < k; ++a) { double acc = lam[a]; for (int q = 0; q < a; ++q) acc = fma(-L[a][q], lam[q], acc); lam[a] = acc / L[a][a]; }
+        for (int a = k - 1; a >= 0; --a) { double acc = lam[a]; for (int q = k - 1; q > a; --q) acc = fma(-L[q][a], lam[q], acc); lam[a] = acc / L[a][a]; }
+        double pn = 0.0;
+        for (int i = 0; i < n; ++i) {
+            double acc = c[i];
+            for (int a = 0; a < k; ++a) acc = fma(-A[(size_t)W[a] * n + i], lam[a], acc);
+            p[i] = acc;
+            if (fabs(acc) > pn) pn = fabs(acc);
+        }
+        if (k == n || pn <= 1e-11 * cn) {
+            /* stationary on the working set: Bland's rule on the multipliers */
+            int drop = -1;
+            for (int a = 0; a < k; ++a)
+                if (lam[a] < -1e-10 * cn && (drop < 0 || W[a] < W[drop])) drop = a;
+            if (drop < 0) break; /* optimal */
+            for (int a = drop; a < k - 1; ++a) W[a] = W[a + 1];
+            --k;
+            continue;
+        }
+        double best = INFINITY;
+        int jb = -1;
+        for (int j = 0; j < m; ++j) {
+            int inW = 0;
+            for (int a = 0; a < k; ++a) if (W[a] == j) inW = 1;
+            if (inW) continue;
+            double ap = 0.0, az = 0.0;
+            for (int i = 0; i < n; ++i) { ap = fma(A[(size_t)j * n + i], p[i], ap); az = fma(A[(size_t)j * n + i], z[i], az); }
+            if (ap > 1e-12 * pn) {
+                double sl = b[j] - az;
+                if (sl < 0.0) sl = 0.0;
+                double r = sl / ap;
+                if (r < best) { best = r; jb = j; }
+            }
+        }
+        if (jb < 0) { status = LBMPC_ST_LP_UNBOUNDED; break; }
+        for (int i = 0; i < n; ++i) z[i] = fma(best, p[i], z[i]);
+        W[k++] = jb;
+    }
+    double val = 0.0;
+    for (int i = 0; i < n; ++i) val = fma(c[i], z[i], val);
+    *value = val;
+    if (zout) for (int i = 0; i < n; ++i) zout[i] = z[i];
+    if (iters_out) *iters_out = iters;
+    return status;
+}
+
+/* h_out[i + nd*s] = max { C[:,i]' z : A z <= b[:,s] } for every direction i and right-hand side s.
+ * A: m x n column-major (rows need not be normalised; they are here), b: m x nb, C: n x nd. */
+int orc_polytope_support(const double* A, int m, int n, const double* b, int64_t nb, const double* Cd, int64_t nd,
+                         double* h_out, double* z_out, int* status_out) {
+    if (!A || !b || !Cd || !h_out || m < 1 || n < 1 || n > LBMPC_MAX_NZ || nb < 0 || nd < 0) return LBMPC_ERR_ARG;
+    double* An = (double*)malloc(sizeof(double) * (size_t)m * n);
+    double* sc = (double*)malloc(sizeof(double) * (size_t)m);
+    double* bn = (double*)malloc(sizeof(double) * (size_t)m);
+    for (int j = 0; j < m; ++j) {
+        double s2 = 0.0;
+        for (int i = 0; i < n; ++i) s2 = fma(CM(A, m, j, i), CM(A, m, j, i), s2);
+        double nr = sqrt(s2);
+        sc[j] = nr > 0.0 ? 1.0 / nr : 0.0;
+        for (int i = 0; i < n; ++i) An[(size_t)j * n + i] = CM(A, m, j, i) * sc[j];
+    }
+    int rc = 0;
+    for (int64_t s = 0; s < nb && !rc; ++s) {
+        for (int j = 0; j < m; ++j) {
+            double bj = b[(size_t)s * m + j];
+            bn[j] = sc[j] > 0.0 ? bj * sc[j] : INFINITY; /* a zero row never blocks */
+            if (!(bj > 0.0)) rc = LBMPC_ERR_ARG;         /* z = 0 must be strictly feasible */
+        }
+        if (rc) break;
+        for (int64_t i = 0; i < nd; ++i) {
+            double c[LBMPC_MAX_NZ], val;
+            for (int q = 0; q < n; ++q) c[q] = Cd[(size_t)i * n + q];
+            int st = lp_support_one(An, bn, m, n, c, &val, z_out ? z_out + ((size_t)s * nd + i) * n : NULL, NULL);
+            h_out[(size_t)s * nd + i] = val;
+            if (status_out) status_out[(size_t)s * nd + i] = st;
+        }
+    }
+    free(An); free(sc); free(bn);
+    return rc;
+}

@@ -74,6 +74,25 @@ def homothety_lp(WA, Wb, m):
     return a, v, mask, st
 
 
+def polytope_support(A, b, Cd, want_z=False):
+    """h[s, i] = max {Cd[:, i]' z : A z <= b[s]}: A m x n, b m or nb x m (all > 0), Cd n x nd.
+    Returns h (nd or nb x nd), status (same shape) and, with want_z, the maximisers (... x n)."""
+    lib = oracle_ffi.load()
+    A, Cd = fcol(A), fcol(Cd)
+    m, n = A.shape
+    B = np.ascontiguousarray(np.atleast_2d(np.asarray(b, dtype=np.float64)))
+    single = np.ndim(b) == 1
+    nb, nd = B.shape[0], Cd.shape[1]
+    h, st = np.zeros((nb, nd)), np.zeros((nb, nd), np.int32)
+    z = np.zeros((nb, nd, n)) if want_z else None
+    rc = lib.orc_polytope_support(dptr(A), m, n, dptr(B), nb, dptr(Cd), nd, dptr(h), dptr(z), iptr(st))
+    assert rc == 0, rc
+    out = (h[0], st[0]) if single else (h, st)
+    if want_z:
+        out = out + ((z[0] if single else z),)
+    return out
+
+
 class Context:
     def __init__(self, params_dict):
         self.lib = oracle_ffi.load()

@@ -299,3 +299,49 @@ def test_oracle_openmp_leg_equals_serial():
     for k in a:
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
     c.close()
+
+
+def _feasible_region_opts(P, api):
+    S = api.Polyhedron(A=P["S_A"], b=P["S_b"])
+    return dict(S=S, S_true=S, S_hat_opt=S, F=P["F"], G=P["G"], K=P["K"], F_bar=P["F_bar"], Psi=P["Psi"],
+                nc=int(P["nc"]), nx=int(P["nx"]), nu=int(P["nu"]), N=int(P["N"]), Ps=P.get("Ps"))
+
+
+def test_feasible_region_golden_parameters_2x2():
+    """ComputeFeasibleRegion on the oracle's LP: hs = stored hs; the exact template of F_N = F_Ns (+) S
+    contains the stored F_N_RMPC vertices (5236 x 2, the hull of 5000 IPOPT projections (+) S) and is tight against
+    them to IPOPT accuracy; Case_5's initial state from the template == from the stored vertices; the polytope-support
+    LP agrees with HiGHS; nu_s: the exact criterion gives 9, and every row block 10..19 (the stored Nu) is redundant,
+    so the stored Omega(1 - hs, 19) is the same set."""
+    import oracle_core
+    from lbmpc import api
+    P = fixtures.params_dict()
+    fr = api.ComputeFeasibleRegion(_feasible_region_opts(P, api), backend=oracle_core.polytope_support)
+    F_N, hs, Nu = fr.ComFeasibleRegion_RMPC()
+    np.testing.assert_allclose(hs.ravel(), P["hs"].ravel(), atol=1.5e-8)
+    V = P["F_N_RMPC_V"]
+    assert (F_N.A @ V.T - F_N.b[:, None]).max() < 2e-7          # stored vertices inside the template
+    assert (F_N.b - (F_N.A @ V.T).max(1)).max() < 3e-7          # and the template is tight against them
+    np.testing.assert_allclose(api.case_5_initial_state(F_N.V), api.case_5_initial_state(V), atol=2e-7)
+    assert Nu == 9 and int(P["Nu"]) == 19
+    H9, hsv = fr._H(9), hs.ravel()
+    later = np.vstack([P["F_bar"] @ np.linalg.matrix_power(P["Psi"], i) for i in range(10, 20)])
+    g, st = oracle_core.polytope_support(H9, np.tile(1 - hsv, 10), later.T)
+    assert st.max() == 0 and (g <= np.tile(1 - hsv, 10) + 1e-12).all()
+    # the literal LP of ComNu_RMPC (M_before only) does not depend on Nu in exact arithmetic
+    vals = []
+    for nu in (8, 9, 12, 15):
+        gl, _ = oracle_core.polytope_support(P["F_bar"] @ np.linalg.matrix_power(P["Psi"], nu), 1 - hsv,
+                                             (P["F_bar"] @ np.linalg.matrix_power(P["Psi"], nu + 1)).T)
+        vals.append(gl)
+    assert np.allclose(vals, vals[0], rtol=1e-7) and (vals[0] > 1 - hsv).any()
+    # LP vs HiGHS on random directions of the 10-variable polytope
+    rng = np.random.default_rng(4)
+    Cd = rng.normal(size=(10, 25))
+    h, st = oracle_core.polytope_support(H9, np.tile(1 - hsv, 10), Cd)
+    for i in range(25):
+        r = linprog(-Cd[:, i], A_ub=H9, b_ub=np.tile(1 - hsv, 10), bounds=[(None, None)] * 10, method="highs")
+        assert st[i] == 0 and abs(-r.fun - h[i]) < 1e-9 * max(1.0, abs(h[i]))
+    # an unbounded direction is reported, not looped on
+    h, st = oracle_core.polytope_support(np.array([[1.0, 0.0]]), np.array([1.0]), np.array([[0.0], [1.0]]))
+    assert st[0] == _abi.ST_LP_UNBOUNDED
