@@ -215,6 +215,36 @@ def main():
         qp_active["C4_4x4_transient"]["note"] = ("the first 32 steps of the C4 launch (pre-pass + transient kernel): every QP of "
                                                  "C4 is solved here; the remaining steps pass the ellipsoid test")
 
+    # ---------------------------------------------------------------- Case_6: UQ-RMPC vs SCMPC (rank 0 only)
+    case6 = None
+    if not args.no_extra_legs and rank == 0:
+        from lbmpc import _abi as abi
+        case6 = {}
+        for name, Pq in (("2x2", params.load(os.path.join(ROOT, "tests", "golden", "params_2x2.npz"))), ("3x3", params.load("3x3"))):
+            nxq, nuq, Nq, ncq = (int(Pq[k]) for k in ("nx", "nu", "N", "nc"))
+            sq = params.sampler(Pq, oriented=True)
+            x0q = np.zeros(nxq); x0q[:2] = [-12.0, 5.0]
+            tr, K6, NSC = 4096, 50, 400 // Nq          # Case_6...:10,25,53: N_Samples = 400, N_SC = N_Samples / N, K_N = 50
+            keep = abi.make_scmpc_params(nxq, nuq, Nq, ncq, NSC, Pq["A"], Pq["B"], np.eye(nxq), 0.1 * np.eye(nuq), Pq["F"], Pq["G"])
+            kw6 = dict(trials=tr, steps=K6, seed=6, x0=x0q, acc_bound=float(np.ravel(Pq["acc_bound"])[0]),
+                       distance_error=float(np.ravel(Pq["distance_error"])[0]))
+            abi.scmpc_mc_run(abi.load(), "lbmpc_", keep, sq, **kw6)
+            t0 = time.perf_counter()
+            rc6, o6 = abi.scmpc_mc_run(abi.load(), "lbmpc_", keep, sq, **kw6)
+            t_sc = time.perf_counter() - t0
+            cq = core.Context(Pq)
+            bq = dev.McBuffers(cq, tr, device)
+            ms_uq = time_launches(lambda: dev.mc_run(cq, sq, bq, steps=K6, card_I0=400, seed=6, x0=x0q, acc_bound=kw6["acc_bound"],
+                                                     distance_error=kw6["distance_error"], trial0=0), 3, warm=1)
+            case6[name] = {"workload": f"{tr} trials x {K6} steps, N_SC={NSC} scenarios x N={Nq} per SCMPC step, card(I0)=400 for UQ-RMPC",
+                           "scmpc_us_per_mpc_step": t_sc / (tr * K6) * 1e6, "scmpc_steps_per_s": tr * K6 / t_sc,
+                           "uqrmpc_us_per_mpc_step": ms_uq * 1e-3 / (tr * K6) * 1e6, "uqrmpc_steps_per_s": tr * K6 / (ms_uq * 1e-3),
+                           "scmpc_infeasible_trials": int(o6["infeasible"].sum()), "scmpc_max_status": int(o6["status"].max()),
+                           "uqrmpc_infeasible_trials": int(bq.infeasible.sum().item()),
+                           "note": "the time table of Case_6...:146-150 (per-step solve time of each controller), batched; SCMPC time "
+                                   "includes its host<->device copies"}
+            cq.close()
+
     # ---------------------------------------------------------------- set learning (C2)
     P2 = params.load(os.path.join(ROOT, "tests", "golden", "params_2x2.npz"))
     smp2 = params.sampler(P2)
@@ -373,6 +403,7 @@ def main():
                                                "write_GBps": sl_bytes / (gen_ms * 1e-3) / 1e9,
                                                "note": "Philox + rejection sampling, VALU/int-bound (3 Philox4x32-10 blocks per sample), writes each sample once"}},
             "support_sweep": sweep,
+            "case_6_scmpc_comparison": case6,
             "mc_stats": {"infeasible_trials": int(infeas.sum().item()), "max_status": int(status.max().item()),
                          "mean_qp_iters_per_trial": float(iters.double().mean().item())},
             "cpu_baseline": cpu,

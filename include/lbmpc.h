@@ -285,6 +285,38 @@ int lbmpc_mc_run_dev(lbmpc_ctx* ctx, const lbmpc_sampler* smp, const lbmpc_mc_cf
                      lbmpc_mc_out* out_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Scenario MPC, the comparison baseline of Case_6
+ * ---------------------------------------------------------------------------------------- */
+
+/* Fields of the struct Functions_general/ScenarioMPC.m:30-48 consumes (Cases_general/Case_6...:22-40). */
+typedef struct lbmpc_scmpc_params {
+    int nx, nu, N, nc;
+    int N_SC;             /* scenarios per step (Case_6...:25: N_Samples / N = 50)        */
+    const double* A;      /* nx x nx */
+    const double* B;      /* nx x nu */
+    const double* Q;      /* nx x nx */
+    const double* R;      /* nu x nu */
+    const double* F;      /* nc x nx */
+    const double* G;      /* nc x nu */
+} lbmpc_scmpc_params;
+
+typedef struct lbmpc_scmpc_out { /* host pointers; any may be NULL */
+    int32_t* infeasible;  /* trials : bound violation flag, as lbmpc_mc_out                 */
+    int32_t* status;      /* trials : max status (LBMPC_ST_QP_INFEASIBLE: scenario QP empty) */
+    int32_t* qp_iters;    /* trials                                                         */
+    double* x_final;      /* nx x trials                                                    */
+    double* traj_x;       /* nx x (steps+1) x traj_trials (State_RM_SCMPC)                  */
+    double* traj_u;       /* nu x steps x traj_trials     (Control_EV_SCMPC)                */
+} lbmpc_scmpc_out;
+
+/* Batched closed loop under ScenarioMPC.solve (ScenarioMPC.m:52-101): per step and trial draw N_SC x N disturbance
+ * scenarios w = xi_EV - xi_LV - B u_LV (:60-68), solve the scenario QP in the N*nu inputs (states eliminated; the
+ * N_SC*N*nc rows F x + G u <= 1 share nc*N normals, so only the tightest scenario per normal is kept: a max-reduction
+ * over the scenarios), apply u_0, step the plant with the SAME step disturbances lbmpc_mc_run uses for these trial ids
+ * (Case_6 runs both controllers against one realisation).  cfg->card_I0 is ignored.  One trial per lane. */
+int lbmpc_scmpc_mc_run(const lbmpc_scmpc_params* p, const lbmpc_sampler* smp, const lbmpc_mc_cfg* cfg, lbmpc_scmpc_out* out);
+
+/* ------------------------------------------------------------------------------------------
  * Feasible-region geometry
  * ---------------------------------------------------------------------------------------- */
 

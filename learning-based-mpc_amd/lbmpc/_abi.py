@@ -52,6 +52,16 @@ class McOut(C.Structure):
                 ("traj_alpha", c_double_p), ("traj_s0", c_double_p)]
 
 
+class ScmpcParams(C.Structure):
+    _fields_ = [("nx", C.c_int), ("nu", C.c_int), ("N", C.c_int), ("nc", C.c_int), ("N_SC", C.c_int)] + [
+        (k, c_double_p) for k in ["A", "B", "Q", "R", "F", "G"]]
+
+
+class ScmpcOut(C.Structure):
+    _fields_ = [("infeasible", c_int32_p), ("status", c_int32_p), ("qp_iters", c_int32_p), ("x_final", c_double_p),
+                ("traj_x", c_double_p), ("traj_u", c_double_p)]
+
+
 def fcol(a):
     """fp64 column-major (MATLAB layout) copy of `a`."""
     return np.asfortranarray(np.asarray(a, dtype=np.float64))
@@ -146,6 +156,7 @@ def declare(lib, prefix):
         "uqmpc_create": [C.POINTER(Params), C.POINTER(vp)],
         "uqmpc_step": [vp, i64, ci, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, ip, ip, ip, ip],
         "mc_run": [vp, C.POINTER(Sampler), C.POINTER(McCfg), C.POINTER(McOut)],
+        "scmpc_mc_run": [C.POINTER(ScmpcParams), C.POINTER(Sampler), C.POINTER(McCfg), C.POINTER(ScmpcOut)],
     }
     for name, args in sig.items():
         f = getattr(lib, prefix + name)
@@ -182,3 +193,25 @@ def load():
             raise ImportError(f"{LIB_PATH} not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
         _lib = declare(C.CDLL(LIB_PATH), "lbmpc_")
     return _lib
+
+
+def make_scmpc_params(nx, nu, N, nc, N_SC, A, B, Q, R, F, G):
+    arr = dict(A=fcol(np.reshape(A, (nx, nx))), B=fcol(np.reshape(B, (nx, nu))), Q=fcol(np.reshape(Q, (nx, nx))),
+               R=fcol(np.reshape(R, (nu, nu))), F=fcol(np.reshape(F, (nc, nx))), G=fcol(np.reshape(G, (nc, nu))))
+    return Keep(ScmpcParams(nx=nx, nu=nu, N=N, nc=nc, N_SC=N_SC, **{k: dptr(v) for k, v in arr.items()}), arr)
+
+
+def scmpc_mc_run(lib, prefix, keep, sampler, trials, steps, seed, x0, acc_bound, distance_error, trial0=0, traj_trials=0,
+                 sampler_max_attempts=1000):
+    """lbmpc_scmpc_mc_run / its oracle twin -> dict of host arrays"""
+    p = keep.struct
+    nx, nu = p.nx, p.nu
+    x0 = fcol(x0).ravel()
+    R = min(traj_trials, trials)
+    o = dict(infeasible=np.zeros(trials, np.int32), status=np.zeros(trials, np.int32), qp_iters=np.zeros(trials, np.int32),
+             x_final=np.zeros((trials, nx)), traj_x=np.zeros((R, steps + 1, nx)), traj_u=np.zeros((R, steps, nu)))
+    cfg = McCfg(trials=trials, trial0=trial0, steps=steps, card_I0=1, seed=seed, x0=dptr(x0), acc_bound=float(acc_bound),
+                distance_error=float(distance_error), traj_trials=R, sampler_max_attempts=sampler_max_attempts)
+    out = ScmpcOut(**{k: (v.ctypes.data_as(c_int32_p) if v.dtype == np.int32 else dptr(v)) for k, v in o.items()})
+    rc = getattr(lib, prefix + "scmpc_mc_run")(keep.ref(), sampler.ref(), C.byref(cfg), C.byref(out))
+    return rc, o

@@ -391,3 +391,42 @@ def case_5_initial_state(V):
     if V.shape[1] >= 2:
         x[1] = V[:, 1].max() - 0.3
     return x
+
+
+class ScenarioMPC:
+    """fields: A, B, N_SC, Q, R, N, F, G, nu, nx, min_u_LV, max_u_LV, Xi_true_EV, Xi_true_LV (ScenarioMPC.m:30-48).
+    solve(x_k) draws N_SC x N fresh scenarios on the device and returns u_k (:52-58); every call consumes the next
+    stream of this object.  scmpc_monte_carlo() below is the batched closed loop."""
+    _calls = itertools.count()
+
+    def __init__(self, parameters, seed=0):
+        p = parameters
+        self.nx, self.nu, self.N = int(p["nx"]), int(p["nu"]), int(p["N"])
+        self.F = np.asarray(p["F"], dtype=np.float64).reshape(-1, self.nx)
+        self.keep = _abi.make_scmpc_params(self.nx, self.nu, self.N, self.F.shape[0], int(p["N_SC"]), p["A"], p["B"], p["Q"],
+                                           np.reshape(p["R"], (self.nu, self.nu)), self.F, p["G"])
+        self.sampler = _abi.make_sampler(self.nx, self.nu, p["Xi_true_EV"].A, p["Xi_true_EV"].b, p["Xi_true_EV"].V,
+                                         p["Xi_true_LV"].A, p["Xi_true_LV"].b, p["Xi_true_LV"].V, p["B"], p["min_u_LV"],
+                                         p["max_u_LV"])
+        self.seed = seed
+
+    def solve(self, x_k):
+        """u_k = obj.solve(x_k)"""
+        lib = core.init()
+        rc, o = _abi.scmpc_mc_run(lib, "lbmpc_", self.keep, self.sampler, trials=1, steps=1, seed=self.seed, x0=np.ravel(x_k),
+                                  acc_bound=np.inf, distance_error=np.inf, trial0=next(ScenarioMPC._calls), traj_trials=1)
+        core._chk(rc, "lbmpc_scmpc_mc_run")
+        self.status = int(o["status"][0])
+        return o["traj_u"][0, 0].reshape(-1, 1)
+
+
+def scmpc_monte_carlo(opts_SCMPC, N_MC, K_N, x_RM_0, acc_bound, distance_error, seed=0, trial0=0, record_trials=0):
+    """Case_6's SCMPC loop (Case_6...:96-150) for N_MC trials at once; trial ids and seed select the same plant
+    disturbances as monte_carlo() with the same arguments."""
+    sc = opts_SCMPC if isinstance(opts_SCMPC, ScenarioMPC) else ScenarioMPC(opts_SCMPC, seed=seed)
+    lib = core.init()
+    rc, o = _abi.scmpc_mc_run(lib, "lbmpc_", sc.keep, sc.sampler, trials=N_MC, steps=K_N, seed=seed, x0=np.ravel(x_RM_0),
+                              acc_bound=acc_bound, distance_error=distance_error, trial0=trial0, traj_trials=record_trials)
+    core._chk(rc, "lbmpc_scmpc_mc_run")
+    return dict(Infeasible_Index=o["infeasible"], status=o["status"], qp_iters=o["qp_iters"], x_K=o["x_final"],
+                State_RM=np.transpose(o["traj_x"], (0, 2, 1)), Control_EV=np.transpose(o["traj_u"], (0, 2, 1)))

@@ -1097,3 +1097,231 @@ int orc_polytope_support(const double* A, int m, int n, const double* b, int64_t
     free(An); free(sc); free(bn);
     return rc;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Scenario MPC (Functions_general/ScenarioMPC.m, Cases_general/Case_6...:96-150), SURVEY.md 8f-3
+ * ---------------------------------------------------------------------------------------- */
+enum { P_SC_U = 6, P_SC_EV = 7, P_SC_LV = 8 };
+#define SC_MAXN LBMPC_MAX_NZ
+#define SC_MAXM (LBMPC_MAX_NZ * LBMPC_MAX_NC)
+
+/* Goldfarb-Idnani for min z'Pz s.t. Cm z <= d from z = 0, Ginv = (2P)^-1: the algorithm of qp_solve above on a
+ * dense row set (most violated row, ties to the lowest; no pivot candidates). */
+static int gi_dense(int n, int m, const double* Cm /* m x n row-major */, const double* d, const double* Ginv,
+                    double* z, int* nact_out, int* iters_out) {
+    int nq = 0, iters = 0, status = 0, act[SC_MAXN];
+    double CA[SC_MAXN][SC_MAXN], Wm[SC_MAXN][SC_MAXN], u[SC_MAXN + 1];
+    for (int k = 0; k < n; ++k) z[k] = 0.0;
+    for (;;) {
+        int p = -1;
+        double sp = -QP_TOL_VIOL;
+        for (int j = 0; j < m; ++j) {
+            int isact = 0;
+            for (int a = 0; a < nq; ++a) if (act[a] == j) isact = 1;
+            if (isact) continue;
+            double s = d[j];
+            for (int k = 0; k < n; ++k) s = fma(-Cm[(size_t)j * n + k], z[k], s);
+            if (s < sp) { sp = s; p = j; }
+        }
+        if (p < 0) break;
+        double cp[SC_MAXN], g[SC_MAXN];
+        for (int k = 0; k < n; ++k) cp[k] = Cm[(size_t)p * n + k];
+        for (int i = 0; i < n; ++i) { double acc = 0.0; for (int k = 0; k < n; ++k) acc = fma(Ginv[i * n + k], cp[k], acc); g[i] = acc; }
+        double cg = 0.0;
+        for (int k = 0; k < n; ++k) cg = fma(cp[k], g[k], cg);
+        u[nq] = 0.0;
+        for (;;) {
+            if (++iters > QP_MAX_ITERS) { status = LBMPC_ST_ITER_CAP; goto done; }
+            double r[SC_MAXN], rhs[SC_MAXN], L[SC_MAXN][SC_MAXN], invd[SC_MAXN], delta = cg;
+            for (int a = 0; a < nq; ++a) { double acc = 0.0; for (int k = 0; k < n; ++k) acc = fma(CA[a][k], g[k], acc); rhs[a] = acc; }
+            for (int a = 0; a < nq; ++a)
+                for (int b = 0; b <= a; ++b) {
+                    double acc = 0.0;
+                    for (int k = 0; k < n; ++k) acc = fma(CA[b][k], Wm[a][k], acc);
+                    for (int k = 0; k < b; ++k) acc = fma(-L[a][k], L[b][k], acc);
+                    if (a == b) { L[a][a] = sqrt(acc > 0.0 ? acc : 0.0); invd[a] = 1.0 / L[a][a]; }
+                    else L[a][b] = acc * invd[b];
+                }
+            for (int a = 0; a < nq; ++a) { double acc = rhs[a]; for (int k = 0; k < a; ++k) acc = fma(-L[a][k], r[k], acc); r[a] = acc * invd[a]; }
+            for (int a = nq - 1; a >= 0; --a) { double acc = r[a]; for (int k = nq - 1; k > a; --k) acc = fma(-L[k][a], r[k], acc); r[a] = acc * invd[a]; }
+            for (int a = 0; a < nq; ++a) delta = fma(-rhs[a], r[a], delta);
+            double zd[SC_MAXN];
+            for (int k = 0; k < n; ++k) { double acc = g[k]; for (int a = 0; a < nq; ++a) acc = fma(-Wm[a][k], r[a], acc); zd[k] = -acc; }
+            int dependent = (nq >= n) || !(delta > QP_TOL_DEP * cg);
+            double t1 = INFINITY, rmax = 0.0;
+            int kdrop = -1;
+            for (int a = 0; a < nq; ++a) if (fabs(r[a]) > rmax) rmax = fabs(r[a]);
+            for (int a = 0; a < nq; ++a)
+                if (r[a] > QP_TOL_R * rmax) { double t = u[a] / r[a]; if (t < t1) { t1 = t; kdrop = a; } }
+            double t2 = dependent ? INFINITY : -sp / delta;
+            double t = t1 < t2 ? t1 : t2;
+            if (t == INFINITY) { status = LBMPC_ST_QP_INFEASIBLE; goto done; }
+            for (int a = 0; a < nq; ++a) u[a] = fma(-t, r[a], u[a]);
+            u[nq] += t;
+            if (!dependent) { for (int k = 0; k < n; ++k) z[k] = fma(t, zd[k], z[k]); sp = fma(t, delta, sp); }
+            if (!dependent && t2 <= t1) {
+                act[nq] = p;
+                memcpy(CA[nq], cp, sizeof(double) * n);
+                memcpy(Wm[nq], g, sizeof(double) * n);
+                nq++;
+                break;
+            }
+            for (int a = kdrop; a < nq - 1; ++a) { act[a] = act[a + 1]; u[a] = u[a + 1]; memcpy(CA[a], CA[a + 1], sizeof(double) * n); memcpy(Wm[a], Wm[a + 1], sizeof(double) * n); }
+            u[nq - 1] = u[nq];
+            nq--;
+        }
+    }
+done:
+    *nact_out = nq;
+    *iters_out = iters;
+    return status;
+}
+
+typedef struct sc_const {
+    int nx, nu, N, nc, n, m, N_SC;
+    double A[16], F[LBMPC_MAX_NC * LBMPC_MAX_NX], B[LBMPC_MAX_NX * LBMPC_MAX_NU];  /* row-major */
+    double GQ[SC_MAXN][SC_MAXN][LBMPC_MAX_NX]; /* [i][j][a] = (Gamma_i' Q)[j][a] */
+    double Cm[SC_MAXM * SC_MAXN];              /* rows (i, r): F_r Gamma_i + G_r e_i' */
+    double Ginv[SC_MAXN * SC_MAXN];            /* (2 P)^-1, P = N_SC (sum_i Gamma_i' Q Gamma_i + blkdiag R) */
+} sc_const;
+
+static int sc_setup(const lbmpc_scmpc_params* p, sc_const* c) {
+    int nx = p->nx, nu = p->nu, N = p->N, nc = p->nc, n = N * nu;
+    if (nx < 1 || nx > LBMPC_MAX_NX || nu < 1 || nu > LBMPC_MAX_NU || n > SC_MAXN || nc < 1 || nc > LBMPC_MAX_NC || p->N_SC < 1) return LBMPC_ERR_DIM;
+    memset(c, 0, sizeof(*c));
+    c->nx = nx; c->nu = nu; c->N = N; c->nc = nc; c->n = n; c->m = N * nc; c->N_SC = p->N_SC;
+    for (int a = 0; a < nx; ++a) for (int b = 0; b < nx; ++b) c->A[a * nx + b] = CM(p->A, nx, a, b);
+    for (int a = 0; a < nx; ++a) for (int j = 0; j < nu; ++j) c->B[a * nu + j] = CM(p->B, nx, a, j);
+    for (int r = 0; r < nc; ++r) for (int b = 0; b < nx; ++b) c->F[r * nx + b] = CM(p->F, nc, r, b);
+    /* Gamma_i (nx x n): column block j <= i is A^(i-j) B */
+    static double Gam[SC_MAXN][LBMPC_MAX_NX][SC_MAXN];
+    double Apow[SC_MAXN][16];
+    for (int a = 0; a < nx; ++a) for (int b = 0; b < nx; ++b) Apow[0][a * nx + b] = (a == b);
+    for (int t = 1; t < N; ++t)
+        for (int a = 0; a < nx; ++a) for (int b = 0; b < nx; ++b) {
+            double acc = 0.0;
+            for (int q = 0; q < nx; ++q) acc = fma(Apow[t - 1][a * nx + q], c->A[q * nx + b], acc);
+            Apow[t][a * nx + b] = acc;
+        }
+    memset(Gam, 0, sizeof(Gam));
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j <= i; ++j)
+            for (int a = 0; a < nx; ++a) for (int l = 0; l < nu; ++l) {
+                double acc = 0.0;
+                for (int q = 0; q < nx; ++q) acc = fma(Apow[i - j][a * nx + q], c->B[q * nu + l], acc);
+                Gam[i][a][j * nu + l] = acc;
+            }
+    double P2[SC_MAXN * SC_MAXN];
+    memset(P2, 0, sizeof(P2));
+    for (int i = 0; i < N; ++i) {
+        for (int j = 0; j < n; ++j) for (int a = 0; a < nx; ++a) {
+            double acc = 0.0;
+            for (int q = 0; q < nx; ++q) acc = fma(Gam[i][q][j], CM(p->Q, nx, q, a), acc);
+            c->GQ[i][j][a] = acc;
+        }
+        for (int j = 0; j < n; ++j) for (int l = 0; l < n; ++l) {
+            double acc = 0.0;
+            for (int a = 0; a < nx; ++a) acc = fma(c->GQ[i][j][a], Gam[i][a][l], acc);
+            P2[j * n + l] += acc;
+        }
+        for (int j = 0; j < nu; ++j) for (int l = 0; l < nu; ++l) P2[(i * nu + j) * n + i * nu + l] += CM(p->R, nu, j, l);
+        for (int r = 0; r < nc; ++r) for (int j = 0; j < n; ++j) {
+            double acc = 0.0;
+            for (int a = 0; a < nx; ++a) acc = fma(c->F[r * nx + a], Gam[i][a][j], acc);
+            if (j / nu == i) acc += CM(p->G, nc, r, j % nu);
+            c->Cm[(size_t)(i * nc + r) * n + j] = acc;
+        }
+    }
+    for (int j = 0; j < n * n; ++j) P2[j] *= 2.0 * (double)p->N_SC;
+    if (!invert_spd_like(n, P2, c->Ginv)) return LBMPC_ERR_ARG;
+    for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) { double s = 0.5 * (c->Ginv[i * n + j] + c->Ginv[j * n + i]); c->Ginv[i * n + j] = c->Ginv[j * n + i] = s; }
+    return 0;
+}
+
+int orc_scmpc_mc_run(const lbmpc_scmpc_params* p, const lbmpc_sampler* smp, const lbmpc_mc_cfg* cfg, lbmpc_scmpc_out* out) {
+    if (!p || !smp || !cfg || !out || !cfg->x0) return LBMPC_ERR_ARG;
+    sc_const* c = (sc_const*)malloc(sizeof(sc_const));
+    int rc = sc_setup(p, c);
+    if (rc) { free(c); return rc; }
+    int nx = c->nx, nu = c->nu, N = c->N, nc = c->nc, n = c->n, m = c->m, K = cfg->steps;
+    for (int64_t t = 0; t < cfg->trials; ++t) {
+        uint64_t tid = (uint64_t)(cfg->trial0 + t);
+        int status = 0, infeasible = 0, iters_total = 0, rec = t < cfg->traj_trials;
+        double x[LBMPC_MAX_NX];
+        memcpy(x, cfg->x0, sizeof(double) * nx);
+        for (int a = 0; a < nx; ++a) if (x[a] > cfg->distance_error || x[a] < -cfg->distance_error) infeasible = 1;
+        if (rec && out->traj_x) memcpy(out->traj_x + ((size_t)t * (K + 1)) * nx, x, sizeof(double) * nx);
+        for (int k = 0; k < K; ++k) {
+            double maxF[SC_MAXM], sum[SC_MAXN][LBMPC_MAX_NX];
+            for (int j = 0; j < m; ++j) maxF[j] = -INFINITY;
+            memset(sum, 0, sizeof(sum));
+            for (int sc = 0; sc < c->N_SC; ++sc) {
+                double phi[LBMPC_MAX_NX];
+                memcpy(phi, x, sizeof(double) * nx);
+                for (int i = 0; i < N; ++i) {
+                    uint32_t idx = (uint32_t)((k * c->N_SC + sc) * N + i);
+                    double u[LBMPC_MAX_NZ], ev[LBMPC_MAX_NX], lv[LBMPC_MAX_NX], Bu[LBMPC_MAX_NX], pn[LBMPC_MAX_NX];
+                    sample_u_lv(smp, cfg->seed, tid, idx, P_SC_U, u);
+                    if (sample_polytope(smp->EV_A, smp->EV_b, smp->nEV, smp->EV_lo, smp->EV_hi, smp->EV_U, nx, cfg->seed, tid, idx, P_SC_EV, cfg->sampler_max_attempts, ev)) status = status > LBMPC_ST_SAMPLER_CAP ? status : LBMPC_ST_SAMPLER_CAP;
+                    if (sample_polytope(smp->LV_A, smp->LV_b, smp->nLV, smp->LV_lo, smp->LV_hi, smp->LV_U, nx, cfg->seed, tid, idx, P_SC_LV, cfg->sampler_max_attempts, lv)) status = status > LBMPC_ST_SAMPLER_CAP ? status : LBMPC_ST_SAMPLER_CAP;
+                    mat_vec(smp->B, nx, nu, u, Bu);
+                    for (int a = 0; a < nx; ++a) {
+                        double acc = 0.0;
+                        for (int b = 0; b < nx; ++b) acc = fma(c->A[a * nx + b], phi[b], acc);
+                        pn[a] = acc + ((ev[a] - lv[a]) - Bu[a]);
+                    }
+                    memcpy(phi, pn, sizeof(double) * nx);
+                    for (int r = 0; r < nc; ++r) {
+                        double f = 0.0;
+                        for (int b = 0; b < nx; ++b) f = fma(c->F[r * nx + b], phi[b], f);
+                        if (f > maxF[i * nc + r]) maxF[i * nc + r] = f;
+                    }
+                    for (int a = 0; a < nx; ++a) sum[i][a] += phi[a];
+                }
+            }
+            double g[SC_MAXN], Uu[SC_MAXN], d[SC_MAXM], z[SC_MAXN];
+            for (int j = 0; j < n; ++j) {
+                double acc = 0.0;
+                for (int i = 0; i < N; ++i) for (int a = 0; a < nx; ++a) acc = fma(c->GQ[i][j][a], sum[i][a], acc);
+                g[j] = acc;
+            }
+            for (int j = 0; j < n; ++j) { double acc = 0.0; for (int l = 0; l < n; ++l) acc = fma(c->Ginv[j * n + l], g[l], acc); Uu[j] = -2.0 * acc; }
+            for (int j = 0; j < m; ++j) {
+                double acc = 0.0;
+                for (int l = 0; l < n; ++l) acc = fma(c->Cm[(size_t)j * n + l], Uu[l], acc);
+                d[j] = (1.0 - maxF[j]) - acc;
+            }
+            int nact = 0, it = 0;
+            int st = gi_dense(n, m, c->Cm, d, c->Ginv, z, &nact, &it);
+            if (st > status) status = st;
+            iters_total += it;
+            double u0[LBMPC_MAX_NU];
+            for (int j = 0; j < nu; ++j) u0[j] = z[j] + Uu[j];
+            /* plant: the step disturbance of lbmpc_mc_run for this (trial, step) */
+            double xi_lv[LBMPC_MAX_NX], xi_ev[LBMPC_MAX_NX], u_lv[LBMPC_MAX_NZ], Bul[LBMPC_MAX_NX], Ax[LBMPC_MAX_NX], Bu2[LBMPC_MAX_NX];
+            if (sample_polytope(smp->LV_A, smp->LV_b, smp->nLV, smp->LV_lo, smp->LV_hi, smp->LV_U, nx, cfg->seed, tid, (uint32_t)k, P_ST_LV, cfg->sampler_max_attempts, xi_lv)) status = status > LBMPC_ST_SAMPLER_CAP ? status : LBMPC_ST_SAMPLER_CAP;
+            sample_u_lv(smp, cfg->seed, tid, (uint32_t)k, P_ST_U, u_lv);
+            if (sample_polytope(smp->EV_A, smp->EV_b, smp->nEV, smp->EV_lo, smp->EV_hi, smp->EV_U, nx, cfg->seed, tid, (uint32_t)k, P_ST_EV, cfg->sampler_max_attempts, xi_ev)) status = status > LBMPC_ST_SAMPLER_CAP ? status : LBMPC_ST_SAMPLER_CAP;
+            mat_vec(smp->B, nx, nu, u_lv, Bul);
+            for (int a = 0; a < nx; ++a) {
+                double acc = 0.0, bcc = 0.0;
+                for (int b = 0; b < nx; ++b) acc = fma(c->A[a * nx + b], x[b], acc);
+                for (int j = 0; j < nu; ++j) bcc = fma(c->B[a * nu + j], u0[j], bcc);
+                Ax[a] = acc; Bu2[a] = bcc;
+            }
+            for (int a = 0; a < nx; ++a) { double wd = (xi_ev[a] - xi_lv[a]) - Bul[a]; x[a] = (Ax[a] + Bu2[a]) + wd; }
+            for (int j = 0; j < nu; ++j) if (u0[j] > cfg->acc_bound || u0[j] < -cfg->acc_bound) infeasible = 1;
+            for (int a = 0; a < nx; ++a) if (x[a] > cfg->distance_error || x[a] < -cfg->distance_error) infeasible = 1;
+            if (rec) {
+                if (out->traj_x) memcpy(out->traj_x + ((size_t)t * (K + 1) + k + 1) * nx, x, sizeof(double) * nx);
+                if (out->traj_u) memcpy(out->traj_u + ((size_t)t * K + k) * nu, u0, sizeof(double) * nu);
+            }
+        }
+        if (out->infeasible) out->infeasible[t] = infeasible;
+        if (out->status) out->status[t] = status;
+        if (out->qp_iters) out->qp_iters[t] = iters_total;
+        if (out->x_final) memcpy(out->x_final + (size_t)t * nx, x, sizeof(double) * nx);
+    }
+    free(c);
+    return 0;
+}

@@ -345,3 +345,60 @@ def test_feasible_region_golden_parameters_2x2():
     # an unbounded direction is reported, not looped on
     h, st = oracle_core.polytope_support(np.array([[1.0, 0.0]]), np.array([1.0]), np.array([[0.0], [1.0]]))
     assert st[0] == _abi.ST_LP_UNBOUNDED
+
+
+def test_scenario_mpc_restatement_against_the_uncondensed_qp():
+    """ScenarioMPC (parity unpinned vs the reference: no stored SCMPC output exists).  The oracle's
+    condensed QP (N inputs, nc*N rows after the max over scenarios) must give the u_0 of the QP exactly as
+    ScenarioMPC.m:70-101 poses it: N_SC*nx*(N+1) states tied by the dynamics, N_SC*N*nc rows, cost
+    sum_k sum_i x'Qx + u'Ru -- solved here by SLSQP on the inputs with all 1600 rows, scenarios re-drawn through the
+    oracle's stand-alone sampler on the same streams."""
+    from scipy.optimize import minimize
+    from lbmpc._abi import make_scmpc_params, scmpc_mc_run
+    P = fixtures.params_dict()
+    lib = oracle_ffi.load()
+    smp = _abi.make_sampler(**fixtures.sampler_args(P))
+    nx, nu, N, nc, N_SC = 2, 1, 8, 4, 50
+    Q, R = np.eye(2), np.array([[0.1]])
+    keep = make_scmpc_params(nx, nu, N, nc, N_SC, P["A"], P["B"], Q, R, P["F"], P["G"])
+    x0 = np.array([-12.0, 5.0])
+    rc, o = scmpc_mc_run(lib, "orc_", keep, smp, trials=2, steps=3, seed=6, x0=x0, acc_bound=2.0, distance_error=15.0, traj_trials=2)
+    assert rc == 0 and o["status"].max() == 0
+    # scenarios of (trial 1, step 0): draws idx = sc*N + i, purposes 6 (u_LV), 7 (xi_EV), 8 (xi_LV)
+    def draw(H, V, purpose, n):
+        A, b = fcol(H[:, :-1]), fcol(H[:, -1]).ravel()
+        lo, hi = fcol(V.min(0)), fcol(V.max(0))
+        out, st = np.zeros((n, A.shape[1])), np.zeros(n, np.int32)
+        assert lib.orc_sample_polytope(dptr(A), dptr(b), A.shape[0], A.shape[1], dptr(lo), dptr(hi), n, 6, 1, 0, purpose, 1000, dptr(out), iptr(st)) == 0
+        return out
+    n = N_SC * N
+    ev, lv = draw(P["Xi_EV_H"], P["Xi_EV_V"], 7, n), draw(P["Xi_LV_H"], P["Xi_LV_V"], 8, n)
+    umin, umax = float(np.ravel(P["min_u_LV"])[0]), float(np.ravel(P["max_u_LV"])[0])
+    ul = draw(np.array([[1.0, umax], [-1.0, -umin]]), np.array([[umin], [umax]]), 6, n)
+    Bm = np.reshape(P["B"], (2, 1))
+    Wsc = (ev - lv - ul @ Bm.T).reshape(N_SC, N, nx)
+    A, F, G = P["A"], P["F"], np.reshape(P["G"], (nc, 1))
+
+    def rollout(U):
+        X = np.zeros((N_SC, N, nx))
+        x = np.tile(x0, (N_SC, 1))
+        for i in range(N):
+            x = x @ A.T + U[i] * Bm.T + Wsc[:, i]
+            X[:, i] = x
+        return X
+
+    def cost(U):
+        X = rollout(U)
+        return float(np.einsum("kia,ab,kib->", X, Q, X) + N_SC * 0.1 * (U ** 2).sum())
+
+    def cons(U):
+        X = rollout(U)
+        return (1.0 - (np.einsum("ra,kia->kir", F, X) + (G[:, 0][None, None, :] * U[None, :, None]))).ravel()
+
+    r = minimize(cost, np.zeros(N), method="SLSQP", constraints=[{"type": "ineq", "fun": cons}], options={"maxiter": 500, "ftol": 1e-12})
+    # SLSQP may stop with "positive directional derivative" at the optimum: judge it by feasibility and by the cost
+    assert cons(r.x).min() > -1e-8
+    print("SLSQP u0", r.x[0], "oracle u0", o["traj_u"][1, 0, 0], r.message)
+    assert abs(r.x[0] - o["traj_u"][1, 0, 0]) < 2e-5 * max(1.0, abs(r.x[0]))
+    # the controller keeps the closed loop inside the bounds on this short run
+    assert o["infeasible"].sum() == 0
