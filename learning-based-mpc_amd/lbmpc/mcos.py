@@ -1,7 +1,9 @@
 """Decode MPT3 `Polyhedron` objects (MATLAB MCOS opaque objects) out of the reference's .mat
 fixtures with scipy only (nothing from the file is executed).  Recipe: SURVEY.md Appendix A.
 
-Used ONLY by tests/golden/make_fixtures.py in the build container, where /root/reference exists.
+Part of the .mat I/O of the package (lbmpc/matio.py: SURVEY.md 8f-4): a user of the reference points the library at
+the parameters_*.mat / Results_*.mat files they already have.  tests/golden/make_fixtures.py uses it in the build
+container to turn the reference's stored data into the committed .npz fixtures.
 """
 import struct
 from io import BytesIO

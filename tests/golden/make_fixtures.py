@@ -3,7 +3,7 @@
 
 Runs ONLY in the build container (needs /root/reference).  It reads data files with scipy
 (`loadmat`, no code execution, no pickle) and decodes the MPT3 Polyhedron objects with
-tests/golden/mcos.py.  No reference source text is copied: the outputs
+lbmpc/mcos.py.  No reference source text is copied: the outputs
 are numeric arrays (inputs + expected outputs of the hot path) stored as .npz (allow_pickle=False).
 
 Fixtures written (all fp64 unless noted):
@@ -21,8 +21,8 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, HERE)
-from mcos import McosFile  # noqa: E402
+sys.path.insert(0, os.path.join(HERE, "..", "..", "learning-based-mpc_amd"))
+from lbmpc.mcos import McosFile  # noqa: E402
 
 REF = os.environ.get("LBMPC_REFERENCE", "/root/reference")
 
