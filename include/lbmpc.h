@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LBMPC_VERSION 110 /* 0.1.1 */
+#define LBMPC_VERSION 111 /* 0.1.1 */
 
 /* usage errors */
 #define LBMPC_ERR_ARG (-1)         /* null pointer / negative size / inconsistent dims      */
@@ -330,6 +330,14 @@ int lbmpc_scmpc_mc_run(const lbmpc_scmpc_params* p, const lbmpc_sampler* smp, co
  * h_{F_N}(d) = h_{F_Ns}(d) + h_{S_hat}(d) needs no hull of 5000 projected samples). */
 int lbmpc_polytope_support(const double* A, int m, int n, const double* b, int64_t nb, const double* C, int64_t nd,
                            double* h_out, double* z_out, int* status_out);
+
+/* Row redundancy of {z : A z <= b} (A: m x n column-major, b > 0): LP j maximises the unit normal of row j over all
+ * the OTHER rows, one LP per lane.  slack_out[j] = b_j/|a_j| - max: >= 0 means the other rows imply row j (redundant),
+ * < 0 that row j cuts; -inf with status LBMPC_ST_LP_UNBOUNDED when only row j bounds that direction.
+ * These are the LPs behind MPT3's minHRep, which the reference calls on every set it builds
+ * (offline_parameters_computation_nxn.m:221-222, :399, :431, :457; Functions_general/ComputeFeasibleRegion.m:112);
+ * duplicate merging and the final keep-list are host logic (lbmpc.api.minHRep). */
+int lbmpc_polytope_redundant(const double* A, int m, int n, const double* b, double* slack_out, int* status_out);
 
 /* ------------------------------------------------------------------------------------------
  * One node, several GPUs, inside one process (the MATLAB drop-in is a single process)

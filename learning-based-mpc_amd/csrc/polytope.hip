@@ -26,12 +26,14 @@ __global__ __launch_bounds__(64) void polytope_support_kernel(const double* __re
                                                               const double* __restrict__ bn /* m x nb, scaled */, int m, int n,
                                                               const double* __restrict__ Cd /* n x nd */, int64_t nd, int64_t nb,
                                                               double* __restrict__ h_out, double* __restrict__ z_out,
-                                                              int* __restrict__ status_out) {
+                                                              int* __restrict__ status_out,
+                                                              const int* __restrict__ skip /* nullable: row LP t ignores */) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = t < nd * nb;
     const int64_t tt = valid ? t : nd * nb - 1;
     const int64_t s = tt / nd, i0 = tt % nd;
     const double* b = bn + (size_t)s * m;
+    const int skipj = skip ? skip[tt] : -1;
     double z[LBMPC_MAX_NZ], p[LBMPC_MAX_NZ], lam[LBMPC_MAX_NZ], c[LBMPC_MAX_NZ], L[LBMPC_MAX_NZ][LBMPC_MAX_NZ];
     int W[LBMPC_MAX_NZ], k = 0, iters = 0, status = 0;
     double cn = 0.0;
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(64) void polytope_support_kernel(const double* __re
                 for (int i = 0; i < n; ++i) { const double aji = row[i]; ap = fma(aji, p[i], ap); az = fma(aji, z[i], az); }
                 bool inW = false;
                 for (int a = 0; a < k; ++a) inW = inW || W[a] == j;
-                if (scan && !inW && ap > 1e-12 * pn) {
+                if (scan && !inW && j != skipj && ap > 1e-12 * pn) {
                     double sl = b[j] - az;
                     if (sl < 0.0) sl = 0.0;
                     const double r = sl / ap;
@@ -142,10 +144,51 @@ extern "C" int lbmpc_polytope_support(const double* A, int m, int n, const doubl
     LB_HIP(hipMemcpy(dC.p, C, (size_t)nd * n * 8, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(polytope_support_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, nullptr, dA.as<double>(),
                        db.as<double>(), m, n, dC.as<double>(), nd, nb, dh.as<double>(), z_out ? dz.as<double>() : nullptr,
-                       status_out ? dst.as<int>() : nullptr);
+                       status_out ? dst.as<int>() : nullptr, nullptr);
     LB_HIP(hipGetLastError());
     LB_HIP(hipMemcpy(h_out, dh.p, (size_t)total * 8, hipMemcpyDeviceToHost));
     if (z_out) LB_HIP(hipMemcpy(z_out, dz.p, (size_t)total * n * 8, hipMemcpyDeviceToHost));
     if (status_out) LB_HIP(hipMemcpy(status_out, dst.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// Row redundancy of {z : A z <= b} (the LPs behind MPT3's minHRep, offline_parameters_computation_nxn.m:221-222,399,
+// ComputeFeasibleRegion.m:112): LP j maximises the unit normal of row j over all the OTHER rows, one lane per row.
+// slack_out[j] = b_j/|a_j| - max: >= 0 means the other rows already imply row j; -inf (status LP_UNBOUNDED) means
+// row j is what bounds that direction.
+extern "C" int lbmpc_polytope_redundant(const double* A, int m, int n, const double* b, double* slack_out, int* status_out) {
+    if (int rc = check_device()) return rc;
+    if (!A || !b || !slack_out || m < 1 || n < 1) { set_error("lbmpc_polytope_redundant: bad argument"); return LBMPC_ERR_ARG; }
+    if (n > LBMPC_MAX_NZ || m > 65536) { set_error("lbmpc_polytope_redundant: n <= %d, m <= 65536", LBMPC_MAX_NZ); return LBMPC_ERR_DIM; }
+    std::vector<double> An((size_t)m * n), bn(m), h(m);
+    std::vector<int> skip(m), st(m);
+    for (int j = 0; j < m; ++j) {
+        double s2 = 0.0;
+        for (int i = 0; i < n; ++i) s2 = std::fma(A[j + (size_t)m * i], A[j + (size_t)m * i], s2);
+        const double nr = std::sqrt(s2);
+        if (!(nr > 0.0)) { set_error("lbmpc_polytope_redundant: row %d is zero", j); return LBMPC_ERR_ARG; }
+        if (!(b[j] > 0.0)) { set_error("lbmpc_polytope_redundant: b[%d] = %g: z = 0 must be strictly feasible", j, b[j]); return LBMPC_ERR_ARG; }
+        const double sc = 1.0 / nr;
+        for (int i = 0; i < n; ++i) An[(size_t)j * n + i] = A[j + (size_t)m * i] * sc;
+        bn[j] = b[j] * sc;
+        skip[j] = j;
+    }
+    DevBuf dA, db, dh, dst, dsk;
+    LB_HIP(dA.alloc(An.size() * 8)); LB_HIP(db.alloc((size_t)m * 8)); LB_HIP(dh.alloc((size_t)m * 8));
+    LB_HIP(dst.alloc((size_t)m * 4)); LB_HIP(dsk.alloc((size_t)m * 4));
+    LB_HIP(hipMemcpy(dA.p, An.data(), An.size() * 8, hipMemcpyHostToDevice));
+    LB_HIP(hipMemcpy(db.p, bn.data(), (size_t)m * 8, hipMemcpyHostToDevice));
+    LB_HIP(hipMemcpy(dsk.p, skip.data(), (size_t)m * 4, hipMemcpyHostToDevice));
+    // direction j = unit row j: the normalised row-major A doubles as the n x nd direction array
+    hipLaunchKernelGGL(polytope_support_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, nullptr, dA.as<double>(),
+                       db.as<double>(), m, n, dA.as<double>(), (int64_t)m, (int64_t)1, dh.as<double>(), nullptr, dst.as<int>(),
+                       dsk.as<int>());
+    LB_HIP(hipGetLastError());
+    LB_HIP(hipMemcpy(h.data(), dh.p, (size_t)m * 8, hipMemcpyDeviceToHost));
+    LB_HIP(hipMemcpy(st.data(), dst.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+    for (int j = 0; j < m; ++j) {
+        slack_out[j] = st[j] == LBMPC_ST_LP_UNBOUNDED ? -INFINITY : bn[j] - h[j];
+        if (status_out) status_out[j] = st[j];
+    }
     return 0;
 }

@@ -153,6 +153,7 @@ def declare(lib, prefix):
         "homothety_lp": [dp, dp, ci, ci, dp, i64, ci, dp, dp, up, ip],
         "sample_polytope": [dp, dp, ci, ci, dp, dp, i64, u64, u64, C.c_uint32, ci, ci, dp, ip],
         "polytope_support": [dp, ci, ci, dp, i64, dp, i64, dp, dp, ip],
+        "polytope_redundant": [dp, ci, ci, dp, dp, ip],
         "uqmpc_create": [C.POINTER(Params), C.POINTER(vp)],
         "uqmpc_step": [vp, i64, ci, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, ip, ip, ip, ip],
         "mc_run": [vp, C.POINTER(Sampler), C.POINTER(McCfg), C.POINTER(McOut)],

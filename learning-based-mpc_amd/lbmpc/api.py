@@ -382,6 +382,74 @@ class ComputeFeasibleRegion:
         return self._hs(S_hat_ini, self.F_Com).reshape(-1, 1)
 
 
+def minHRep(P, tol=1e-9, return_keep=False):
+    """MPT3's minHRep for a full-dimensional polytope in H-rep: drop the rows the others imply.
+    (offline_parameters_computation_nxn.m:221-222, :399; ComputeFeasibleRegion.m:112.)  The m redundancy LPs
+    (maximise a_j over the rows != j) run on the device, one per lane (lbmpc_polytope_redundant); host logic:
+    shift an interior point to 0, merge parallel duplicates (keep the tightest), drop the rows whose LP value stays
+    within tol of b_j, then CHECK the result with one more batched LP -- every dropped normal's support over the
+    kept rows must stay <= b_j + 10 tol, else the row is put back.  Returns Polyhedron(A, b[, V]) (+ kept row ids)."""
+    A, b = np.asarray(P.A, dtype=np.float64), np.asarray(P.b, dtype=np.float64).ravel()
+    x0 = np.zeros(A.shape[1])
+    if not np.all(b > 0):
+        if P.V is None:
+            raise ValueError("minHRep: 0 is not strictly inside and no vertices are known to find an interior point")
+        x0 = P.V.mean(0)
+    bs = b - A @ x0
+    if not np.all(bs > 0):
+        raise ValueError("minHRep: the polytope has no interior at the vertex mean (lower-dimensional set?)")
+    nr = np.linalg.norm(A, axis=1)
+    An, bn = A / nr[:, None], bs / nr
+    order = np.lexsort(np.vstack([bn, np.round(An, 9).T[::-1]]))   # by direction, tightest first within a direction
+    uniq = []
+    for j in order:
+        if uniq and np.abs(An[j] - An[uniq[-1]]).max() <= 1e-9:
+            continue
+        uniq.append(int(j))
+    uniq = np.array(sorted(uniq))
+    slack, st = core.polytope_redundant(An[uniq], bn[uniq])
+    if np.any((st != 0) & (st != _abi.ST_LP_UNBOUNDED)):
+        raise RuntimeError(f"minHRep: redundancy LP failed with status {int(st.max())}")
+    red = slack >= -tol
+    keep, drop = uniq[~red], uniq[red]
+    if len(drop) and len(keep):
+        h, st2 = core.polytope_support(An[keep], bn[keep], An[drop].T)
+        back = (st2 != 0) | (h > bn[drop] + 10 * tol)
+        keep = np.sort(np.concatenate([keep, drop[back]]))
+    elif not len(keep):
+        keep = uniq
+    out = Polyhedron(A=A[keep], b=b[keep], V=P.V)
+    return (out, keep) if return_keep else out
+
+
+def hull(V):
+    """Polyhedron('V', V) with both representations: extreme points and facets of conv(V) (qhull on the host, as
+    MPT3 calls CDD; triangulated facets of one plane are merged)"""
+    from scipy.spatial import ConvexHull
+    V = np.asarray(V, dtype=np.float64)
+    ch = ConvexHull(V)
+    eq = ch.equations
+    H = np.hstack([eq[:, :-1], -eq[:, -1:]])
+    H = H[np.lexsort(np.round(H, 9).T[::-1])]
+    keep = [0]
+    for i in range(1, len(H)):
+        if np.abs(H[i] - H[keep[-1]]).max() > 1e-9:
+            keep.append(i)
+    H = H[keep]
+    return Polyhedron(V=V[np.sort(ch.vertices)], A=H[:, :-1], b=H[:, -1])
+
+
+def minkowski_sum(*vertex_sets):
+    """P1 (+) P2 (+) ... from vertex lists (MPT3's `+` on Polyhedra, offline_parameters_computation_nxn.m:166):
+    hull of all vertex sums, facets pruned by minHRep on the device"""
+    acc = np.asarray(vertex_sets[0], dtype=np.float64)
+    for V in vertex_sets[1:]:
+        V = np.asarray(V, dtype=np.float64)
+        acc = (acc[:, None, :] + V[None, :, :]).reshape(-1, acc.shape[1])
+        acc = hull(acc).V
+    return minHRep(hull(acc))
+
+
 def case_5_initial_state(V):
     """x_RM_0 of Case_5...:45-47 from the vertices of F_N_Hat: first coordinate 0.1 inside the lower extreme, second
     0.3 inside the upper extreme, the rest 0"""

@@ -149,6 +149,18 @@ def polytope_support(A, b, Cd, want_z=False):
     return out
 
 
+def polytope_redundant(A, b):
+    """slack[j] = b_j/|a_j| - max {a_j' z / |a_j| : rows != j}: >= 0 where row j is implied by the others, -inf where
+    only row j bounds its direction (lbmpc_polytope_redundant; needs b > 0).  Returns (slack, status)."""
+    lib = init()
+    A = fcol(A)
+    m, n = A.shape
+    bb = np.ascontiguousarray(np.asarray(b, dtype=np.float64).ravel())
+    slack, st = np.zeros(m), np.zeros(m, np.int32)
+    _chk(lib.lbmpc_polytope_redundant(dptr(A), m, n, dptr(bb), dptr(slack), iptr(st)), "lbmpc_polytope_redundant")
+    return slack, st
+
+
 class Context:
     """Device-resident controller constants (lbmpc_uqmpc_create / lbmpc_destroy)."""
 

@@ -146,6 +146,17 @@ def save_parameters(path, P):
            "Xi_true_EV": car["Xi_true_EV"], "Xi_true_LV": car["Xi_true_LV"], "N_pre_sam": 100.0,
            "N_sam_opt": float(np.ravel(P.get("N_sam_opt", 0))[0])}
     top = {"opts_UQMPC": U, "opts_RMPC": U, "opts_Car": car, "opts_ini_set": ini}
+    if "Ps" in P and P["Ps"] is not None:
+        U["Ps"] = _f64(P["Ps"])
+    if "S_true_H" in P and "S_hat_opt_H" in P:   # what ComputeFeasibleRegion's constructor reads (:31-46)
+        fea = {k: U[k] for k in ("F", "G", "K", "F_bar", "Psi", "nc", "nx", "nu", "N", "num_half_space_S", "hs") if k in U}
+        fea.update(S=U["S"], S_true=poly("S_true"), S_hat_opt=poly("S_hat_opt"))
+        if "Ps" in U:
+            fea["Ps"] = U["Ps"]
+        top["opts_feasible_region"] = fea
+    for k in ("F_N_RMPC", "F_N_True", "F_N_Hat_Opt"):   # the reference stores these as vertex arrays
+        if k + "_V" in P:
+            top[k] = _f64(P[k + "_V"])
     for k in ("x_des", "distance_error", "acc_bound", "T"):
         if k in P:
             top[k] = _f64(P[k]).reshape(-1, 1)

@@ -996,7 +996,7 @@ int orc_mc_run_omp(orc_ctx* c, const lbmpc_sampler* smp, const lbmpc_mc_cfg* cfg
 
 
 static int lp_support_one(const double* A /* m x n row-major, unit rows */, const double* b, int m, int n,
-                          const double* c, double* value, double* zout, int* iters_out) {
+                          const double* c, double* value, double* zout, int* iters_out, int skip /* row ignored, -1: none */) {
     double z[LBMPC_MAX_NZ], p[LBMPC_MAX_NZ], lam[LBMPC_MAX_NZ], L[LBMPC_MAX_NZ][LBMPC_MAX_NZ];
     int W[LBMPC_MAX_NZ], k = 0, iters = 0, status = 0;
     double cn = 0.0;
@@ -1041,7 +1041,7 @@ static int lp_support_one(const double* A /* m x n row-major, unit rows */, cons
         for (int j = 0; j < m; ++j) {
             int inW = 0;
             for (int a = 0; a < k; ++a) if (W[a] == j) inW = 1;
-            if (inW) continue;
+            if (inW || j == skip) continue;
             double ap = 0.0, az = 0.0;
             for (int i = 0; i < n; ++i) { ap = fma(A[(size_t)j * n + i], p[i], ap); az = fma(A[(size_t)j * n + i], z[i], az); }
             if (ap > 1e-12 * pn) {
@@ -1089,12 +1089,38 @@ int orc_polytope_support(const double* A, int m, int n, const double* b, int64_t
         for (int64_t i = 0; i < nd; ++i) {
             double c[LBMPC_MAX_NZ], val;
             for (int q = 0; q < n; ++q) c[q] = Cd[(size_t)i * n + q];
-            int st = lp_support_one(An, bn, m, n, c, &val, z_out ? z_out + ((size_t)s * nd + i) * n : NULL, NULL);
+            int st = lp_support_one(An, bn, m, n, c, &val, z_out ? z_out + ((size_t)s * nd + i) * n : NULL, NULL, -1);
             h_out[(size_t)s * nd + i] = val;
             if (status_out) status_out[(size_t)s * nd + i] = st;
         }
     }
     free(An); free(sc); free(bn);
+    return rc;
+}
+
+/* Row redundancy (the LPs behind MPT3's minHRep, offline_parameters_computation_nxn.m:221-222,399): LP j maximises
+ * the unit normal of row j over all the other rows; slack_out[j] = b_j/|a_j| - max (-inf when unbounded). */
+int orc_polytope_redundant(const double* A, int m, int n, const double* b, double* slack_out, int* status_out) {
+    if (!A || !b || !slack_out || m < 1 || n < 1 || n > LBMPC_MAX_NZ) return LBMPC_ERR_ARG;
+    double* An = (double*)malloc(sizeof(double) * (size_t)m * n);
+    double* bn = (double*)malloc(sizeof(double) * (size_t)m);
+    int rc = 0;
+    for (int j = 0; j < m; ++j) {
+        double s2 = 0.0;
+        for (int i = 0; i < n; ++i) s2 = fma(CM(A, m, j, i), CM(A, m, j, i), s2);
+        double nr = sqrt(s2);
+        if (!(nr > 0.0) || !(b[j] > 0.0)) { rc = LBMPC_ERR_ARG; break; }
+        double sc = 1.0 / nr;
+        for (int i = 0; i < n; ++i) An[(size_t)j * n + i] = CM(A, m, j, i) * sc;
+        bn[j] = b[j] * sc;
+    }
+    for (int j = 0; j < m && !rc; ++j) {
+        double val;
+        int st = lp_support_one(An, bn, m, n, An + (size_t)j * n, &val, NULL, NULL, j);
+        slack_out[j] = st == LBMPC_ST_LP_UNBOUNDED ? -INFINITY : bn[j] - val;
+        if (status_out) status_out[j] = st;
+    }
+    free(An); free(bn);
     return rc;
 }
 

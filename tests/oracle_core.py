@@ -93,6 +93,17 @@ def polytope_support(A, b, Cd, want_z=False):
     return out
 
 
+def polytope_redundant(A, b):
+    lib = oracle_ffi.load()
+    A = fcol(A)
+    m, n = A.shape
+    bb = np.ascontiguousarray(np.asarray(b, dtype=np.float64).ravel())
+    slack, st = np.zeros(m), np.zeros(m, np.int32)
+    rc = lib.orc_polytope_redundant(dptr(A), m, n, dptr(bb), dptr(slack), iptr(st))
+    assert rc == 0, rc
+    return slack, st
+
+
 class Context:
     def __init__(self, params_dict):
         self.lib = oracle_ffi.load()

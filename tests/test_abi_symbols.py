@@ -26,7 +26,7 @@ def test_header_symbols_exported():
     assert len(names) >= 17
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.lbmpc_version() == 110
+    assert lib.lbmpc_version() == 111
 
 
 def test_struct_layouts_match_c():

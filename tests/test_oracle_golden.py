@@ -402,3 +402,42 @@ def test_scenario_mpc_restatement_against_the_uncondensed_qp():
     assert abs(r.x[0] - o["traj_u"][1, 0, 0]) < 2e-5 * max(1.0, abs(r.x[0]))
     # the controller keeps the closed loop inside the bounds on this short run
     assert o["infeasible"].sum() == 0
+
+
+def test_redundancy_lps_against_highs():
+    """orc_polytope_redundant (the LPs behind minHRep) vs scipy's HiGHS on a random polytope"""
+    import oracle_core
+    rng = np.random.default_rng(77)
+    n, m = 3, 60
+    D = rng.normal(size=(m, n))
+    D /= np.linalg.norm(D, axis=1, keepdims=True)
+    b = 1.0 + 0.5 * rng.random(m)
+    slack, st = oracle_core.polytope_redundant(D, b)
+    for j in range(m):
+        others = np.arange(m) != j
+        res = linprog(-D[j], A_ub=D[others], b_ub=b[others], bounds=[(None, None)] * n, method="highs")
+        if res.status == 3:
+            assert st[j] == _abi.ST_LP_UNBOUNDED and slack[j] == -np.inf
+        else:
+            assert res.status == 0 and st[j] == 0
+            assert abs((b[j] + res.fun) - slack[j]) < 1e-9, j
+
+
+def test_compute_Ps_is_the_centred_minimum_volume_ellipsoid():
+    """pipeline.compute_Ps: the vertex form (offline_parameters_computation.m:137-154) reproduces the Ps stored in
+    parameters_2x2.mat; the row form (nxn script :827-848) satisfies the KKT conditions of its own problem"""
+    from lbmpc import pipeline
+    g = fixtures.npz("params_2x2.npz")
+    Pv = pipeline.compute_Ps(g["F_bar"], g["Psi"], int(g["Nu"]), g["hs"], over="vertices")
+    assert np.abs(Pv - g["Ps"]).max() <= 1e-5 * np.abs(g["Ps"]).max()      # SDPT3 accuracy of the stored value
+    Ps = pipeline.compute_Ps(g["F_bar"], g["Psi"], int(g["Nu"]))
+    H = np.vstack([g["F_bar"] @ np.linalg.matrix_power(g["Psi"], i) for i in range(int(g["Nu"]) + 1)])
+    nr = np.linalg.norm(H @ Ps.T, axis=1)
+    assert nr.max() <= 1 + 1e-9
+    # KKT of max logdet X s.t. h_i' X h_i <= 1: X^-1 = sum lam_i h_i h_i', lam >= 0 supported on the active rows
+    from scipy.optimize import nnls
+    X = Ps @ Ps
+    act = nr > 1 - 1e-6
+    Amat = np.stack([np.outer(h, h).ravel() for h in H[act]], 1)
+    lam, res = nnls(Amat, np.linalg.inv(X).ravel())
+    assert res <= 1e-5 * np.linalg.norm(np.linalg.inv(X))
