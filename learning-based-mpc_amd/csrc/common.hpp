@@ -272,17 +272,17 @@ int pack_box(const double* WA, const double* Wb, int nW, int nx, BoxW* out);  //
 // Closed form of the homothety LP for a box W with the LBMPC_TIE_CENTER rule; `m` in canonical
 // row order.  Same operation order as orc_homothety_box.
 template <int NX>
-__device__ __forceinline__ int homothety_box(const BoxW* __restrict__ bw, const double* m, double& alpha,
-                                             double* v, uint32_t& mask) {
+__device__ __forceinline__ int homothety_box_rows(const double* Wb, const double* ic, const double* m, double& alpha,
+                                                  double* v, uint32_t& mask) {
     double Bp[NX], Bq[NX], Mp[NX], Mq[NX], rho[NX];
     bool infeas = false;
     double a = 0.0;
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
         const int p = 2 * k, q = 2 * k + 1;
-        Bp[k] = bw->Wb[p] * bw->ic[p]; Bq[k] = bw->Wb[q] * bw->ic[q];
-        Mp[k] = m[p] * bw->ic[p];      Mq[k] = m[q] * bw->ic[q];
-        infeas = infeas || (m[p] > bw->Wb[p]) || (m[q] > bw->Wb[q]);
+        Bp[k] = Wb[p] * ic[p]; Bq[k] = Wb[q] * ic[q];
+        Mp[k] = m[p] * ic[p];      Mq[k] = m[q] * ic[q];
+        infeas = infeas || (m[p] > Wb[p]) || (m[q] > Wb[q]);
         rho[k] = (Mp[k] + Mq[k]) / (Bp[k] + Bq[k]);
         a = rho[k] > a ? rho[k] : a;
     }
@@ -306,6 +306,12 @@ __device__ __forceinline__ int homothety_box(const BoxW* __restrict__ bw, const 
     }
     alpha = a; mask = mk;
     return 0;
+}
+
+template <int NX>
+__device__ __forceinline__ int homothety_box(const BoxW* __restrict__ bw, const double* m, double& alpha,
+                                             double* v, uint32_t& mask) {
+    return homothety_box_rows<NX>(bw->Wb, bw->ic, m, alpha, v, mask);
 }
 
 }  // namespace lbmpc

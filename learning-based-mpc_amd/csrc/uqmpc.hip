@@ -18,299 +18,11 @@
 //   * long horizons run in step segments: mc_kernel for the transient, mc_steady_kernel (no solver, several blocks per
 //     CU) for the steps where no trial needs a QP, and a resume launch of mc_kernel for the trials that did after all.
 // Constants ([S_b | S_A] rows in fp64 and fp32, F_bar Psi^i rows, (2P)^-1) are staged once per block into LDS.
-#include <algorithm>
-#include <cmath>
-#include <cstdlib>
-#include <cstring>
-#include <vector>
-
-#include "common.hpp"
-
-namespace lbmpc {
-
-#define QP_TOL_VIOL 1e-10
-#define QP_TOL_DEP 1e-13
-#define QP_TOL_R 1e-12
-#define QP_MAX_ITERS 200
-#define NZMAX LBMPC_MAX_NZ
-
-struct CtxDev {
-    int nx, nu, N, nc, Nu, nS, nW, nz, nH, RL, nzp, nSp;  // nSp: S row storage padded to a multiple of 128
-    double A[LBMPC_MAX_NX * LBMPC_MAX_NX];    // row-major
-    double B[LBMPC_MAX_NX * LBMPC_MAX_NU];    // row-major nx x nu
-    double K[LBMPC_MAX_NU * LBMPC_MAX_NX];    // row-major nu x nx
-    double T[LBMPC_MAX_NX * LBMPC_MAX_NX];    // (I-Phi)^-1 row-major
-    double FcT[LBMPC_MAX_NC * LBMPC_MAX_NX];  // (F+GK) T row-major
-    double hs[LBMPC_MAX_NC];
-    BoxW box;
-    const double* Srow;  // nSp x RL : [S_b[j], S_A[j,0..nx-1]], RL = nx + 1
-    const float* S32;    // fp32 copy for the first-pass filter, row PAIRS interleaved: [b_j b_j+1 a_j0 a_j+1,0 ...]
-    double amax[LBMPC_MAX_NX], bmax;  // max_j |S_A[j,k]|, max_j |S_b[j]|: rounding margin of the filter
-    // inscribed ellipsoid E = {x : x' ME x <= 1} of S (centred at 0): q' ME q <= (alpha (1-1e-6))^2 proves that no S
-    // row is violated at z = 0 (Cauchy-Schwarz: |a_j.q| <= sqrt(a_j' ME^-1 a_j) sqrt(q' ME q) <= b_j alpha (1-1e-6))
-    double ME[LBMPC_MAX_NX * LBMPC_MAX_NX], bmin;
-    double cmH[LBMPC_MAX_NZ];  // max_h |H[h,k]|: certificate that no H row is violated (qp_group.hpp, scan_rows)
-    int hasE;
-    int lane_solver;     // 1: try the one-QP-per-lane solver of the S-row regime first (qp_lane.hpp)
-    const double* Hm;    // nH x nzp: rows of F_bar Psi^i, i = 0..Nu
-    const double* Ginv;  // nz x nz : (2 blkdiag(Px,Pc))^-1
-};
-
-}  // namespace lbmpc
-
-struct lbmpc_ctx {
-    lbmpc::CtxDev h;          // host copy (device pointers inside)
-    lbmpc::CtxDev* d = nullptr;
-    double *dS = nullptr, *dH = nullptr, *dG = nullptr;
-    float* dS32 = nullptr;
-    int device = 0;
-    size_t lds_const_bytes = 0;
-    // grow-only scratch of lbmpc_mc_run: pre-drawn step disturbances of one trial chunk (+ their cap flags)
-    double* xi = nullptr;
-    size_t xi_bytes = 0;
-    int* xi_status = nullptr;
-    size_t xi_status_n = 0;
-    unsigned long long* counters = nullptr;  // 12 work counters of the last mc_run
-    int* hint = nullptr;                     // pivot candidates, 17 ints per chunk trial (16 rows + count)
-    size_t hint_n = 0;
-    double* st_d = nullptr;                  // trial state handed between step segments: (3 nx + 1) doubles ...
-    int* st_i = nullptr;                     // ... and 5 ints per chunk trial
-    size_t st_n = 0;
-    double* park = nullptr;                  // state parked during solves, PARK_SLOTS doubles per grid thread
-    size_t park_bytes = 0;
-};
-
-namespace lbmpc {
-
-struct LdsView {
-    const double* Srow;
-    const double* Hm;
-    const double* Ginv;
-    const float* S32;
-};
-// LDS layout (doubles): [S rows | H rows | Ginv | pad to even | S32 (floats) | per-wave solver slots]
-__host__ __device__ inline int lds_const_doubles(const CtxDev& h) {
-    const int d64 = (h.nSp * h.RL + h.nH * h.nzp + h.nz * h.nz + 1) & ~1;
-    return d64 + (h.nSp * h.RL + 1) / 2;
-}
-__host__ __device__ inline int ws_doubles(int) { return 4 * 48; }  // GWS_PER_WAVE: four row slots per wave
-
-}  // namespace lbmpc
-
+#include "uqmpc_dev.hpp"
 #include "qp_group.hpp"
 #include "qp_lane.hpp"
 
 namespace lbmpc {
-
-// ---- lane-per-trial pieces ----------------------------------------------------------------------
-
-// W_A[r,:] . x for canonical row r.  For an exact box (every off-axis coefficient an exact zero: all reference
-// configurations) the fma chain of the dense form collapses to its one non-zero term, fma(a, x_k, 0.0), bit for bit
-// (the other terms add exact zeros; a zero product gives +0.0 in both forms).
-template <int NX>
-__device__ __forceinline__ double box_row_dot(const CtxDev* __restrict__ C, int r, const double* x) {
-    if (C->box.exact) return fma(C->box.WA[r * NX + (r >> 1)], x[r >> 1], 0.0);
-    double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < NX; ++k) t = fma(C->box.WA[r * NX + k], x[k], t);
-    return t;
-}
-
-// b_hat = alpha W_b + (1-alpha) W_A v (canonical row order)
-template <int NX>
-__device__ __forceinline__ void w_hat_b(const CtxDev* __restrict__ C, double alpha, const double* v, double* bh) {
-#pragma unroll
-    for (int r = 0; r < 2 * NX; ++r) {
-        const double t = box_row_dot<NX>(C, r, v);
-        bh[r] = alpha * C->box.Wb[r] + (1.0 - alpha) * t;
-    }
-}
-
-// Online set update LPforUQ (UQRobustMPC.m:124-139): homothety LP on m = max(b_hat_prev, W_A w_new);
-// (alpha, v) unchanged when w_new is inside W_hat_prev.
-template <int NX>
-__device__ __forceinline__ int uq_update(const CtxDev* __restrict__ C, double& alpha, double* v, const double* w, double* bh,
-                                         bool* changed = nullptr) {
-    double mm[2 * NX];
-    bool outside = false;
-    int st = 0;
-    w_hat_b<NX>(C, alpha, v, bh);
-#pragma unroll
-    for (int r = 0; r < 2 * NX; ++r) {
-        const double hw = box_row_dot<NX>(C, r, w);
-        mm[r] = bh[r];
-        if (hw > bh[r]) { mm[r] = hw; outside = true; }
-    }
-    if (outside) {
-        uint32_t mask;
-        st = homothety_box<NX>(&C->box, mm, alpha, v, mask);
-        w_hat_b<NX>(C, alpha, v, bh);
-    }
-    if (changed) *changed = outside;
-    return st;
-}
-
-// q = (1-alpha) T v - x ; returns min_r (1 - h_k[r]) and its first index (h_k closed form :80-84)
-template <int NX>
-__device__ __forceinline__ void tighten(const CtxDev* __restrict__ C, double alpha, const double* v, const double* x,
-                                        double* q, double& min_omh, int& arg_omh) {
-    const double beta = 1.0 - alpha;
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        double acc = 0.0;
-#pragma unroll
-        for (int k = 0; k < NX; ++k) acc = fma(C->T[i * NX + k], v[k], acc);
-        q[i] = beta * acc - x[i];
-    }
-    min_omh = LB_INF; arg_omh = 0;
-    for (int r = 0; r < C->nc; ++r) {
-        double g = 0.0;
-#pragma unroll
-        for (int k = 0; k < NX; ++k) g = fma(C->FcT[r * NX + k], v[k], g);
-        double omh = 1.0 - (alpha * C->hs[r] + beta * g);
-        if (omh < min_omh) { min_omh = omh; arg_omh = r; }
-    }
-}
-
-// the part of tighten() that depends on (alpha, v) only: bTv = (1-alpha) T v, min_r (1 - h_k[r]) and its index
-template <int NX>
-__device__ __forceinline__ void tighten_set(const CtxDev* __restrict__ C, double alpha, const double* v, double* bTv,
-                                            double& min_omh, int& arg_omh) {
-    const double beta = 1.0 - alpha;
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        double acc = 0.0;
-#pragma unroll
-        for (int k = 0; k < NX; ++k) acc = fma(C->T[i * NX + k], v[k], acc);
-        bTv[i] = beta * acc;
-    }
-    min_omh = LB_INF; arg_omh = 0;
-    for (int r = 0; r < C->nc; ++r) {
-        double g = 0.0;
-#pragma unroll
-        for (int k = 0; k < NX; ++k) g = fma(C->FcT[r * NX + k], v[k], g);
-        double omh = 1.0 - (alpha * C->hs[r] + beta * g);
-        if (omh < min_omh) { min_omh = omh; arg_omh = r; }
-    }
-}
-
-template <int NX>
-__device__ __forceinline__ double hk_value(const CtxDev* __restrict__ C, double alpha, const double* v, int r) {
-    double g = 0.0;
-#pragma unroll
-    for (int k = 0; k < NX; ++k) g = fma(C->FcT[r * NX + k], v[k], g);
-    return alpha * C->hs[r] + (1.0 - alpha) * g;
-}
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// One chunk of 8 rows (4 interleaved row pairs), packed fp32: per pair 1 pk_mul + NX pk_fma + 1 min3.
-template <int NX, int T>
-__device__ __forceinline__ void first_pass_eval(const float4* cur, const float* af, const float (*qf)[NX], float* mn) {
-    constexpr int RLc = NX + 1, CH = 2 * RLc;  // float4 loads per chunk
-    float cf[8 * RLc];
-#pragma unroll
-    for (int i = 0; i < CH; ++i) { cf[4 * i] = cur[i].x; cf[4 * i + 1] = cur[i].y; cf[4 * i + 2] = cur[i].z; cf[4 * i + 3] = cur[i].w; }
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-#pragma unroll
-        for (int pr = 0; pr < 4; ++pr) {
-            const float* r = cf + pr * 2 * RLc;
-            f32x2 acc = (f32x2){af[t], af[t]} * (f32x2){r[0], r[1]};
-#pragma unroll
-            for (int k = 0; k < NX; ++k)
-                acc = __builtin_elementwise_fma((f32x2){r[2 + 2 * k], r[3 + 2 * k]}, (f32x2){qf[t][k], qf[t][k]}, acc);
-            mn[t] = __builtin_fminf(__builtin_fminf(acc.x, acc.y), mn[t]);
-        }
-    }
-}
-
-// First stage of the first-pass filter, the inscribed ellipsoid of S (CtxDev::ME): outside[t] = the trial is NOT
-// proven free of violated S rows.
-template <int NX, int T>
-__device__ __forceinline__ bool ellipsoid_outside(const CtxDev* __restrict__ C, const double* alpha, const double (*q)[NX],
-                                                  bool* outside) {
-    bool any = false;
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        double e2 = 0.0;
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            double ti = 0.0;
-#pragma unroll
-            for (int k = 0; k < NX; ++k) ti = fma(C->ME[i * NX + k], q[t][k], ti);
-            e2 = fma(q[t][i], ti, e2);
-        }
-        const double as = alpha[t] * (1.0 - 1e-6);
-        // slack_j >= alpha 1e-6 b_j must clear the tolerance and the rounding of the exact evaluation
-        const bool inside = C->hasE && alpha[t] * 1e-6 * C->bmin >= 1e-9 && e2 <= as * as;
-        outside[t] = !inside;
-        any = any || !inside;
-    }
-    return any;
-}
-
-// Second stage, the packed-fp32 scan of the S rows at z = 0 for the T trials of this lane: may any S row be violated?  slack_j = alpha S_b[j] + S_A[j,:].q ; the
-// H rows contribute exactly 1-h_k[r] (min_omh, exact).  This is only a FILTER in front of the exact solver (whose
-// own fp64 scan decides, and returns z = 0 after zero iterations when nothing is violated), so it runs in packed
-// fp32 -- every row pair is one LDS broadcast shared by the 64*T trials of the wave -- and flags a trial whenever
-// the fp32 minimum is below -tol + margin, margin = 2^-20 (alpha max|S_b| + sum_k max|S_A[:,k]| |q_k|) >= twice the
-// worst-case rounding error (gamma_7, u = 2^-24) of any row.  A violated row is therefore never missed; a false
-// alarm costs one scan.  NaN / overflow compare as "flagged".
-template <int NX, int T>
-__device__ __forceinline__ void filter_scan(const CtxDev* __restrict__ C, const LdsView& L, const double* alpha,
-                                            const double (*q)[NX], bool* need) {
-    constexpr int RLc = NX + 1;
-    constexpr int CH = 2 * RLc;
-    float mn[T], af[T], qf[T][NX];
-    double thresh[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        mn[t] = __builtin_inff();
-        af[t] = (float)alpha[t];
-        double e = fabs(alpha[t]) * C->bmax;
-#pragma unroll
-        for (int k = 0; k < NX; ++k) { qf[t][k] = (float)q[t][k]; e = fma(C->amax[k], fabs(q[t][k]), e); }
-        thresh[t] = -QP_TOL_VIOL + 0x1p-20 * e;
-    }
-    const int nch = C->nSp >> 3;       // chunks of 8 rows; even: nSp is a multiple of 128
-    const float4* p = reinterpret_cast<const float4*>(L.S32);
-    float4 bufA[CH], bufB[CH];
-#pragma unroll
-    for (int i = 0; i < CH; ++i) bufA[i] = p[i];
-    // ping-pong: the next chunk is in flight while the current one is evaluated
-    for (int c = 0; c < nch; c += 2) {
-        const float4* pb = p + (size_t)(c + 1) * CH;
-#pragma unroll
-        for (int i = 0; i < CH; ++i) bufB[i] = pb[i];
-        __builtin_amdgcn_sched_barrier(0);
-        first_pass_eval<NX, T>(bufA, af, qf, mn);
-        const float4* pa = p + (size_t)(c + 2 < nch ? c + 2 : 0) * CH;
-#pragma unroll
-        for (int i = 0; i < CH; ++i) bufA[i] = pa[i];
-        __builtin_amdgcn_sched_barrier(0);
-        first_pass_eval<NX, T>(bufB, af, qf, mn);
-    }
-#pragma unroll
-    for (int t = 0; t < T; ++t) need[t] = !((double)mn[t] >= thresh[t]);
-}
-
-template <int NX, int T>
-__device__ __forceinline__ bool first_pass(const CtxDev* __restrict__ C, const LdsView& L, const double* alpha,
-                                           const double (*q)[NX], const double* min_omh, bool* need) {
-    bool outside[T];
-    const bool any = ellipsoid_outside<NX, T>(C, alpha, q, outside);
-    bool scanned = false;
-#pragma unroll
-    for (int t = 0; t < T; ++t) need[t] = false;
-    if (__builtin_amdgcn_ballot_w64(any) != 0) {
-        filter_scan<NX, T>(C, L, alpha, q, need);
-        scanned = true;
-    }
-#pragma unroll
-    for (int t = 0; t < T; ++t) need[t] = need[t] || (min_omh[t] < -QP_TOL_VIOL);
-    return scanned;  // the rows were scanned
-}
 
 // Copies the constants into LDS and returns the view; *ws_base = first per-wave solver slot.
 __device__ __forceinline__ LdsView stage_constants(const CtxDev* __restrict__ C, double* lds, double** ws_base) {
@@ -522,79 +234,6 @@ __global__ __launch_bounds__(256) void uqmpc_step_kernel(const CtxDev* __restric
         if (io.n_active) io.n_active[b] = nact;
         if (io.qp_iters) io.qp_iters[b] = iters;
     }
-}
-
-// ---- closed-loop Monte-Carlo kernel ---------------------------------------------------------------
-struct McArgs {
-    int64_t trials, trial0;
-    int steps, card_I0;
-    uint64_t seed;
-    double x0[LBMPC_MAX_NX];
-    double acc_bound, distance_error;
-    int traj_trials, sampler_max_attempts;
-    int tpw;  // trials per wave (and per t): 4 .. 64
-    // step segment of this launch: [kseg0, kseg1); resume != 0: every trial continues from its saved state at step
-    // st_i[kpos] (trials whose kpos is not inside the segment idle); state is saved at the end when kseg1 < steps
-    int kseg0, kseg1, resume;
-    double* st_d;  // [3 nx + 1][chunk trial]: x, v, w_new, alpha
-    int* st_i;     // [5][chunk trial]: status, infeasible, iters, hashint, kpos
-    // this launch covers local trials [chunk0, chunk0 + chunk_n); xi holds their pre-drawn step disturbances
-    int64_t chunk0, chunk_n;
-    const double* xi;       // pre-drawn step disturbances, layout xi_index()
-    const int* xi_status;   // [chunk trial] LBMPC_ST_SAMPLER_CAP if a step sampler hit the attempt cap
-    unsigned long long* counters;  // 12 work counters of this launch
-    int* hint;              // [chunk trial][16] final active set of the trial's previous step (pivot candidates)
-    int* nhint;             // [chunk trial] its size
-    double* park;           // [slot][thread of the grid]: closed-loop state parked during a solve (mc_kernel)
-    lbmpc_mc_out out;
-};
-
-// Layout of the pre-drawn step disturbances w = (xi_EV - xi_LV) - B u_LV: [step][chunk trial][nx] with chunk trials
-// padded to a multiple of 4.  A closed-loop step reads one contiguous 64*nx*8-byte window per wave; the pre-pass
-// writes it in full lines (4 trials per thread).
-template <int NX>
-__host__ __device__ inline int64_t xi_index(int64_t cl, int k, int64_t chunk_n) {
-    const int64_t np = (chunk_n + 3) & ~(int64_t)3;
-    return ((int64_t)k * np + cl) * NX;
-}
-__host__ inline size_t xi_bytes_for(int nx, int K, int64_t chunk_n) {
-    return (size_t)K * (size_t)((chunk_n + 3) & ~(int64_t)3) * nx * 8;
-}
-
-// ---- step-disturbance pre-pass ------------------------------------------------------------------------
-// w = (xi_EV - xi_LV) - B u_LV of every (trial, step): xi_* by rejection sampling (ModelingCar.m:36-43 via :47-91), in
-// the form the information set uses (InitialSetComputation.m:51-52).  The draws depend on (seed, trial, step, attempt)
-// only, not on the closed-loop state, so they are produced ahead of the closed loop, one trial per lane, step by step:
-// the wave's stores of a step are one contiguous 64*nx*8-byte run of the step-major layout.  A wave repeats a draw
-// until its last lane has accepted (sample_polytope): free with the tight proposal boxes (lbmpc_sampler.EV_U / LV_U:
-// acceptance ~1), a few extra attempts per draw with loose axis-aligned ones.  grid.y splits the steps into equal
-// segments (more waves in flight).  3 Philox blocks per trial-step.
-template <int NX>
-__global__ __launch_bounds__(256) void mc_sample_kernel(SamplerDev smp, int64_t chunk_n, int64_t trial_first, int K,
-                                                        uint64_t seed, int max_attempts, double* __restrict__ xi,
-                                                        int* __restrict__ xi_status) {
-    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = l < chunk_n;
-    const int64_t cl = valid ? l : chunk_n - 1;   // idle lanes of the last wave repeat the last trial (no stores)
-    const uint64_t tid = (uint64_t)(trial_first + cl);
-    const int seg = (K + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int kbeg = (int)blockIdx.y * seg < K ? (int)blockIdx.y * seg : K;
-    const int kend = kbeg + seg < K ? kbeg + seg : K;
-    bool cap = false;
-    for (int k = kbeg; k < kend; ++k) {
-        double lv[NX], ev[NX], Bul[NX];
-        if (smp.LV_hasU) cap |= sample_polytope<NX>(smp.LV_A, smp.LV_b, smp.nLV, smp.LV_lo, smp.LV_hi, smp.LV_U, seed, tid, (uint32_t)k, P_ST_LV, max_attempts, lv);
-        else cap |= sample_polytope<NX>(smp.LV_A, smp.LV_b, smp.nLV, smp.LV_lo, smp.LV_hi, nullptr, seed, tid, (uint32_t)k, P_ST_LV, max_attempts, lv);
-        sample_Bu_lv<NX>(&smp, seed, tid, (uint32_t)k, P_ST_U, Bul);
-        if (smp.EV_hasU) cap |= sample_polytope<NX>(smp.EV_A, smp.EV_b, smp.nEV, smp.EV_lo, smp.EV_hi, smp.EV_U, seed, tid, (uint32_t)k, P_ST_EV, max_attempts, ev);
-        else cap |= sample_polytope<NX>(smp.EV_A, smp.EV_b, smp.nEV, smp.EV_lo, smp.EV_hi, nullptr, seed, tid, (uint32_t)k, P_ST_EV, max_attempts, ev);
-        if (valid) {
-            double* dst = xi + xi_index<NX>(cl, k, chunk_n);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) dst[i] = (ev[i] - lv[i]) - Bul[i];
-        }
-    }
-    if (valid && cap) atomicMax(&xi_status[cl], (int)LBMPC_ST_SAMPLER_CAP);
 }
 
 #ifdef LBMPC_PROFILE
@@ -914,148 +553,6 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
     }
 #endif
 }
-// ---- steady-state closed loop -----------------------------------------------------------------------
-// After the transient no trial needs a QP (C4: none after step 8 of 1000): a step is the set update, the kept
-// tightening, the first-pass filter (ellipsoid test; packed-fp32 row scan when a lane is outside) and the plant update
-// with z = 0.  This kernel runs exactly those steps, lane per trial, with none of the solver's registers or LDS (only
-// the fp32 S rows are staged): several blocks per CU instead of 2 waves per SIMD, so the per-step latencies overlap.
-// A trial whose filter asks for a QP stops with its state saved BEFORE that step; the resume launch of mc_kernel
-// takes it from there (same arithmetic, so the split is invisible in the results).
-template <int NX>
-__global__ __launch_bounds__(256) void mc_steady_kernel(const CtxDev* __restrict__ C, McArgs a) {
-    extern __shared__ double lds[];
-    float* s32 = reinterpret_cast<float*>(lds);
-    {
-        const int n = C->nSp * C->RL;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) s32[i] = C->S32[i];
-        __syncthreads();
-    }
-    LdsView L;
-    L.Srow = nullptr; L.Hm = nullptr; L.Ginv = nullptr; L.S32 = s32;
-    const int nu = C->nu, K = a.steps;
-    const int64_t cn = a.chunk_n;
-    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = l < cn;
-    const int64_t c = valid ? l : cn - 1;
-    const int64_t tl = a.chunk0 + c;
-    unsigned nfilter = 0, nsteps = 0;
-    double x[NX], v[NX], wst[NX], alpha;
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        x[i] = a.st_d[(0 * NX + i) * cn + c]; v[i] = a.st_d[(1 * NX + i) * cn + c]; wst[i] = a.st_d[(2 * NX + i) * cn + c];
-    }
-    alpha = a.st_d[3 * NX * cn + c];
-    int status = a.st_i[0 * cn + c], infeasible = a.st_i[1 * cn + c];
-    bool hashint = a.st_i[3 * cn + c] != 0;
-    bool active = valid && a.st_i[4 * cn + c] == a.kseg0;
-    bool stale = true;
-    double bTv[NX], momh_c = 0.0;
-#pragma unroll
-    for (int i = 0; i < NX; ++i) bTv[i] = 0.0;
-    for (int k = a.kseg0; k < a.kseg1; ++k) {
-        if (__builtin_amdgcn_ballot_w64(active) == 0) break;
-        double wk[NX];
-        {
-            const double* xw = a.xi + xi_index<NX>(c, k, cn);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) wk[i] = xw[i];
-        }
-        // online set update on a copy: committed only if the trial does not stop at this step
-        double an[1] = {alpha}, vn[NX], bh[2 * NX], q[1][NX];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) vn[i] = v[i];
-        bool changed = false;
-        const int st = uq_update<NX>(C, an[0], vn, wst, bh, &changed);
-        int aomh;
-        if (__builtin_amdgcn_ballot_w64(changed || stale) != 0) {
-            tighten_set<NX>(C, an[0], vn, bTv, momh_c, aomh);
-            stale = false;
-        }
-#pragma unroll
-        for (int i = 0; i < NX; ++i) q[0][i] = bTv[i] - x[i];
-        bool outside[1], need = momh_c < -QP_TOL_VIOL;
-        (void)ellipsoid_outside<NX, 1>(C, an, q, outside);
-        outside[0] = outside[0] && active;
-        nsteps += 1;
-        if (__builtin_amdgcn_ballot_w64(outside[0]) != 0) {
-            bool nf[1];
-            filter_scan<NX, 1>(C, L, an, q, nf);
-            need = need || (nf[0] && outside[0]);
-            nfilter += 1;
-        }
-        if (active && need) {  // hand this trial to the solver kernel, state as it was before this step
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                a.st_d[(0 * NX + i) * cn + c] = x[i]; a.st_d[(1 * NX + i) * cn + c] = v[i]; a.st_d[(2 * NX + i) * cn + c] = wst[i];
-            }
-            a.st_d[3 * NX * cn + c] = alpha;
-            a.st_i[0 * cn + c] = status; a.st_i[1 * cn + c] = infeasible;
-            a.st_i[3 * cn + c] = hashint ? 1 : 0; a.st_i[4 * cn + c] = k;
-            active = false;
-        }
-        if (active) {
-            alpha = an[0];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) v[i] = vn[i];
-            status = st > status ? st : status;
-            if (hashint) { a.nhint[c] = 0; hashint = false; }  // no QP this step: no pivot candidates next step
-            // u = K x (c = 0); plant update in relative coordinates, as in mc_kernel
-            double u[LBMPC_MAX_NU], Ax[NX], Bu[NX], xn[NX];
-#pragma unroll
-            for (int j = 0; j < LBMPC_MAX_NU; ++j) {
-                u[j] = 0.0;
-                if (j < nu) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) acc = fma(C->K[j * NX + i], x[i], acc);
-                    u[j] = acc;
-                    if (acc > a.acc_bound || acc < -a.acc_bound) infeasible = 1;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                double acc = 0.0, bcc = 0.0;
-#pragma unroll
-                for (int kk = 0; kk < NX; ++kk) acc = fma(C->A[i * NX + kk], x[kk], acc);
-#pragma unroll
-                for (int j = 0; j < LBMPC_MAX_NU; ++j) if (j < nu) bcc = fma(C->B[i * nu + j], u[j], bcc);
-                Ax[i] = acc; Bu[i] = bcc;
-                xn[i] = (Ax[i] + Bu[i]) + wk[i];
-            }
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                wst[i] = (xn[i] - Ax[i]) - Bu[i];
-                x[i] = xn[i];
-                if (xn[i] > a.distance_error || xn[i] < -a.distance_error) infeasible = 1;
-            }
-            if (tl < a.traj_trials) {
-                if (a.out.traj_x) for (int i = 0; i < NX; ++i) a.out.traj_x[(tl * (K + 1) + k + 1) * NX + i] = x[i];
-                if (a.out.traj_u) for (int j = 0; j < nu; ++j) {
-                    double uj = 0.0;
-#pragma unroll
-                    for (int jj = 0; jj < LBMPC_MAX_NU; ++jj) if (jj == j) uj = u[jj];
-                    a.out.traj_u[(tl * K + k) * nu + j] = uj;
-                }
-                if (a.out.traj_alpha) a.out.traj_alpha[tl * (K + 1) + k + 1] = alpha;
-                if (a.out.traj_s0) for (int i = 0; i < NX; ++i) a.out.traj_s0[(tl * K + k) * NX + i] = 0.0;
-            }
-        }
-    }
-    if (active) {  // reached the end of the segment (= the horizon: this kernel always runs to a.steps)
-        a.st_i[4 * cn + c] = a.kseg1;
-        if (a.out.infeasible) a.out.infeasible[tl] = infeasible;
-        if (a.out.status) a.out.status[tl] = status;
-        if (a.out.qp_iters) a.out.qp_iters[tl] = a.st_i[2 * cn + c];
-        if (a.out.alpha_final) a.out.alpha_final[tl] = alpha;
-        if (a.out.v_final) for (int i = 0; i < NX; ++i) a.out.v_final[tl * NX + i] = v[i];
-        if (a.out.x_final) for (int i = 0; i < NX; ++i) a.out.x_final[tl * NX + i] = x[i];
-    }
-    if (lane_id() == 0 && a.counters) {
-        atomicAdd(a.counters + 0, (unsigned long long)nfilter);
-        atomicAdd(a.counters + 1, (unsigned long long)nsteps);
-    }
-}
-
 #ifdef LBMPC_PROFILE
 extern "C" int lbmpc_prof_read_waves(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(lbmpc_prof_wave), sizeof(unsigned long long) * 3 * 4096) == hipSuccess ? 0 : -1;
@@ -1420,8 +917,9 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
     int ksplit = cfg->steps >= 64 ? 32 : cfg->steps;
     if (const char* env_s = getenv("LBMPC_MC_SPLIT")) { const int v = atoi(env_s); ksplit = (v > 0 && v < cfg->steps) ? v : cfg->steps; }
     const char* env_l = getenv("LBMPC_MC_LEAN");
-    const bool lean = !(env_l && atoi(env_l) == 0);
-    const size_t lds_steady = (((size_t)c->h.nSp * c->h.RL * 4 + 15) / 16) * 16;
+    // the steady-state kernel is written for an exact box W and one input (every reference configuration)
+    const bool lean = !(env_l && atoi(env_l) == 0) && c->h.box.exact && c->h.nu == 1;
+    const size_t lds_steady = steady_lds_bytes(c->h.nSp, c->h.RL, c->h.nx);
     if (ksplit < cfg->steps && (size_t)chunk > c->st_n) {
         if (c->st_d) LB_HIP(hipFree(c->st_d));
         if (c->st_i) LB_HIP(hipFree(c->st_i));
@@ -1444,13 +942,7 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
             segs = segs < 1 ? 1 : (segs > 64 ? 64 : segs);
             if (segs > cfg->steps) segs = cfg->steps;
             dim3 sg((unsigned)sblocks, (unsigned)segs), sb(256);
-            switch (c->h.nx) {
-                case 1: hipLaunchKernelGGL((mc_sample_kernel<1>), sg, sb, 0, st, sd, cn, cfg->trial0 + c0, cfg->steps, cfg->seed, cfg->sampler_max_attempts, c->xi, c->xi_status); break;
-                case 2: hipLaunchKernelGGL((mc_sample_kernel<2>), sg, sb, 0, st, sd, cn, cfg->trial0 + c0, cfg->steps, cfg->seed, cfg->sampler_max_attempts, c->xi, c->xi_status); break;
-                case 3: hipLaunchKernelGGL((mc_sample_kernel<3>), sg, sb, 0, st, sd, cn, cfg->trial0 + c0, cfg->steps, cfg->seed, cfg->sampler_max_attempts, c->xi, c->xi_status); break;
-                default: hipLaunchKernelGGL((mc_sample_kernel<4>), sg, sb, 0, st, sd, cn, cfg->trial0 + c0, cfg->steps, cfg->seed, cfg->sampler_max_attempts, c->xi, c->xi_status); break;
-            }
-            LB_HIP(hipGetLastError());
+            if (int rc = launch_mc_sample(c->h.nx, sg, sb, st, sd, cn, cfg->trial0 + c0, cfg->steps, cfg->seed, cfg->sampler_max_attempts, c->xi, c->xi_status)) return rc;
         }
         int64_t blocks = (cn + per_block - 1) / per_block;
         const int64_t resident = 256 * (int64_t)(LDS_LIMIT / lds > 4 ? 4 : (LDS_LIMIT / lds < 1 ? 1 : LDS_LIMIT / lds));
@@ -1488,19 +980,7 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
             a.kseg0 = ksplit; a.kseg1 = cfg->steps; a.resume = 1;
             if (lean) {
                 dim3 g2((unsigned)((cn + 255) / 256)), b2(256);
-#define LAUNCH_STEADY(KERN)                                                                     \
-    do {                                                                                        \
-        if (int rc = allow_lds(KERN, lds_steady)) return rc;                                    \
-        hipLaunchKernelGGL((KERN), g2, b2, lds_steady, st, c->d, a);                            \
-    } while (0)
-                switch (c->h.nx) {
-                    case 1: LAUNCH_STEADY(mc_steady_kernel<1>); break;
-                    case 2: LAUNCH_STEADY(mc_steady_kernel<2>); break;
-                    case 3: LAUNCH_STEADY(mc_steady_kernel<3>); break;
-                    default: LAUNCH_STEADY(mc_steady_kernel<4>); break;
-                }
-#undef LAUNCH_STEADY
-                LB_HIP(hipGetLastError());
+                if (int rc = launch_mc_steady(c, g2, b2, lds_steady, st, a)) return rc;
             }
             LAUNCH_MC_ALL();   // trials whose saved step is before the horizon's end (all of them without the lean kernel)
         }

@@ -2,7 +2,7 @@
 # kernel times of a diagnostic library build ($1 = path of the .so) on the bench workload ($BENCH_ARGS: extra bench.py flags)
 cd "$(dirname "$0")/.."
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-LBMPC_LIB=$PWD/$1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --sl-sets 64 $BENCH_ARGS > gpurun_out/abl.log 2>&1
+rm -rf gpurun_out/abl; LBMPC_LIB=$PWD/$1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abl -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --sl-sets 64 $BENCH_ARGS > gpurun_out/abl.log 2>&1
 f=$(find gpurun_out/abl -name "*kernel_stats.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys
