@@ -375,7 +375,8 @@ int lbmpc_halfspace_max_multi(const double* WA, int nW, int nx, const double* sa
  * each), out[1] wave-steps in total, out[2] QP solves, then the 16-lane-row solver: out[3] rounds (up to 4 QPs each),
  * out[4] loop trips, out[5] full pivot scans (4 QPs each), out[6] passes over the H rows inside them (2 QPs each);
  * the one-QP-per-lane solver of the S-row regime: out[7] loop trips (up to 64 QPs each), out[8] scan passes over
- * the S rows (up to 4 QPs each); out[9] QPs that went through the 16-lane-row solver; out[10..11] reserved. */
+ * the S rows (up to 4 QPs each); out[9] QPs that went through the 16-lane-row solver; out[10] QPs served by the scan passes of out[8];
+ * out[11] reserved. */
 int lbmpc_mc_counters(lbmpc_ctx* ctx, uint64_t* out12);
 
 #ifdef __cplusplus

@@ -72,7 +72,7 @@ __device__ __forceinline__ void scan_S_lanes(const CtxDev* __restrict__ C, const
 // Solve the QPs of the lanes flagged in `need` (one per lane).  On return, for every flagged lane either
 // fallback = true (nothing else is meaningful, the hint list is untouched) or z[0..NX) = s0 (the rest of z is 0),
 // status, iters, nact, act[0..nact) (insertion order) are those of the oracle's qp_solve, and the lane's hint list in
-// HBM holds this solve's active set.  ctr[0] += loop trips, ctr[1] += scan passes (wave-uniform).
+// HBM holds this solve's active set.  ctr[0] += loop trips, ctr[1] += scan passes, ctr[3] += QPs served by them (wave-uniform).
 template <int NX>
 __device__ __forceinline__ void lane_qp_solve(const CtxDev* __restrict__ C, const LdsView& L, bool need, double alpha,
                                               const double* q, double min_omh, int* hint_rows /* this lane's 16 slots or null */,
@@ -110,17 +110,21 @@ __device__ __forceinline__ void lane_qp_solve(const CtxDev* __restrict__ C, cons
 #pragma unroll
         for (int k = 0; k < NX; ++k) Gi[i][k] = L.Ginv[i * nz + k];
 
+    bool pending = false;   // this lane waits for a full scan (its z does not move meanwhile)
     while (__builtin_amdgcn_ballot_w64(!done) != 0) {
         ctr[0] += 1;
         // ---- Step 1: a violated row at the current z for the lanes without a pivot ----
-        const bool s1 = !done && !have_p;
+        // Candidates are evaluated by the lane itself; a lane that needs the full scan waits until four such lanes can
+        // share one pass over the rows (or until no other lane of the wave has a step 2 to do): a pass costs the same
+        // for one QP as for four, and per lane the sequence of operations is unchanged.
+        const bool s1 = !done && !have_p && !pending;
+        double best = -QP_TOL_VIOL;
+        int bj = 0x7fffffff;
+        bool got = false;   // the lane has a step-1 result to act on in this trip
         if (__builtin_amdgcn_ballot_w64(s1) != 0) {
             double e[NX];
 #pragma unroll
             for (int k = 0; k < NX; ++k) e[k] = q[k] + z[k];
-            double best = -QP_TOL_VIOL;
-            int bj = 0x7fffffff;
-            bool need_full = s1;
             if (__builtin_amdgcn_ballot_w64(s1 && nh > 0) != 0) {   // candidates first, in list order
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
@@ -135,40 +139,60 @@ __device__ __forceinline__ void lane_qp_solve(const CtxDev* __restrict__ C, cons
                     for (int k = 0; k < NX; ++k) acc = fma(row[1 + k], e[k], acc);
                     if (ev && (acc < best || (acc == best && bj != 0x7fffffff && j < bj))) { best = acc; bj = j; }
                 }
-                if (bj != 0x7fffffff) need_full = false;
             }
+            const bool need_full = s1 && bj == 0x7fffffff;
             if (__builtin_amdgcn_ballot_w64(need_full) != 0) {
                 // certificate that no H row is violated at z (z is zero beyond NX)
                 double t = 0.0;
 #pragma unroll
                 for (int k = 0; k < NX; ++k) t = fma(C->cmH[k], fabs(z[k]), t);
-                if (need_full && !(t <= min_omh - 1e-9)) { fallback = true; done = true; need_full = false; }
-                uint64_t mask = __builtin_amdgcn_ballot_w64(need_full);
-                while (mask) {
+                if (need_full) {
+                    if (!(t <= min_omh - 1e-9)) { fallback = true; done = true; }
+                    else pending = true;
+                }
+            }
+            got = s1 && !pending && !done;
+        }
+        uint64_t pm = __builtin_amdgcn_ballot_w64(pending);
+        if (pm != 0) {
+            const bool others = __builtin_amdgcn_ballot_w64(!done && !pending && (have_p || got)) != 0;
+            const int np = __builtin_popcountll(pm);
+            int nscan = others ? (np & ~3) : np;
+            if (nscan > 0) {
+                double e[NX];
+#pragma unroll
+                for (int k = 0; k < NX; ++k) e[k] = q[k] + z[k];
+                bool scanned = false;
+                while (nscan > 0) {
                     ctr[1] += 1;
                     int src[4];
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
-                        src[gq] = mask ? (int)__builtin_ctzll(mask) : -1;
-                        if (mask) mask &= mask - 1;
+                        const bool take = pm != 0 && nscan > 0;
+                        src[gq] = take ? (int)__builtin_ctzll(pm) : -1;
+                        if (take) { pm &= pm - 1; nscan -= 1; ctr[3] += 1; }
                     }
                     double fb[4];
                     int fj[4];
                     scan_S_lanes<NX>(C, L, src, alpha, e, fb, fj);
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq)
-                        if (lane == src[gq]) { best = fb[gq]; bj = fj[gq]; }
+                        if (lane == src[gq]) { best = fb[gq]; bj = fj[gq]; scanned = true; }
                 }
-                if (need_full) {   // an active row never wins a scan (its slack is ~0 > -tol); if one does, leave this path
+                if (scanned) {   // an active row never wins a scan (its slack is ~0 > -tol); if one does, leave this path
+                    pending = false;
                     bool isact = false;
 #pragma unroll
                     for (int a = 0; a < NX; ++a) isact = isact || (a < nq && act[a] == bj);
                     if (isact) { fallback = true; done = true; }
+                    got = !done;
                 }
             }
-            const bool optimal = s1 && !done && bj == 0x7fffffff;
+        }
+        {
+            const bool optimal = got && !done && bj == 0x7fffffff;
             done = done || optimal;
-            const bool newp = s1 && !done;
+            const bool newp = got && !done;
             if (__builtin_amdgcn_ballot_w64(newp) != 0) {
                 // c_p = -S_A[p,:], g = Ginv c_p, cg = c_p . g
                 const double* row = L.Srow + (newp ? bj : 0) * (NX + 1) + 1;
@@ -193,8 +217,8 @@ __device__ __forceinline__ void lane_qp_solve(const CtxDev* __restrict__ C, cons
                 }
             }
         }
-        // ---- Step 2 for every lane that is not done ----
-        const bool act2 = !done;
+        // ---- Step 2 for every lane that has a pivot ----
+        const bool act2 = !done && !pending;
         if (act2) {
             iters += 1;
             if (iters > QP_MAX_ITERS) { status = LBMPC_ST_ITER_CAP; done = true; }

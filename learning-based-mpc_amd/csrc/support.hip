@@ -41,25 +41,73 @@ __global__ __launch_bounds__(256) void support_kernel(const double* __restrict__
         sum[u] = 0.0;
     }
     const double* __restrict__ g = G;
-    for (int t = 0; t < s; ++t) {
-        double best[DPL];
+    if ((nV & 3) == 0) {
+        // Rows in groups of four, double-buffered in SGPRs: the scalar loads of the next group are in flight while the
+        // current one feeds the FMAs (scalar loads return out of order, so the only wait there is waits for all of
+        // them: issued one group ahead, that wait falls after a group's worth of arithmetic).  nV % 4 == 0: a group
+        // never straddles two t.
+        const int gpt = nV >> 2, ngroups = s * gpt;
+        double aA[4][NX], aB[4][NX], best[DPL];
 #pragma unroll
         for (int u = 0; u < DPL; ++u) best[u] = -LB_INF;
-#pragma unroll 4  // four G rows per scalar-load wait
-        for (int v = 0; v < nV; ++v, g += NX) {
-            double a[NX];
+        auto load4 = [&](double (*a)[NX], const double* src) {
 #pragma unroll
-            for (int k = 0; k < NX; ++k) a[k] = g[k];
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int u = 0; u < DPL; ++u) {
-                double acc = 0.0;
+                for (int k = 0; k < NX; ++k) a[r][k] = src[r * NX + k];
+        };
+        int gin = 0;   // group index inside the current t
+        auto compute4 = [&](const double (*a)[NX]) {
 #pragma unroll
-                for (int k = 0; k < NX; ++k) acc = fma(a[k], d[u][k], acc);
-                best[u] = acc > best[u] ? acc : best[u];
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int u = 0; u < DPL; ++u) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) acc = fma(a[r][k], d[u][k], acc);
+                    best[u] = __builtin_fmax(acc, best[u]);
+                }
+            if (++gin == gpt) {
+                gin = 0;
+#pragma unroll
+                for (int u = 0; u < DPL; ++u) { sum[u] += best[u]; best[u] = -LB_INF; }
             }
+        };
+        load4(aA, g);
+        const int npairs = ngroups >> 1;
+        for (int pi = 0; pi < npairs; ++pi) {   // branch-free body: the last pair loads group ngroups-1 (or itself) again
+            asm volatile("" ::"s"(aA[0][0]));   // the wait for A comes before B's loads are issued
+            load4(aB, g + 4 * NX);
+            __builtin_amdgcn_sched_barrier(0);
+            compute4(aA);
+            asm volatile("" ::"s"(aB[0][0]));
+            load4(aA, 2 * pi + 2 < ngroups ? g + 8 * NX : g);
+            __builtin_amdgcn_sched_barrier(0);
+            compute4(aB);
+            g += 8 * NX;
         }
+        if (ngroups & 1) compute4(aA);
+    } else {
+        for (int t = 0; t < s; ++t) {
+            double best[DPL];
 #pragma unroll
-        for (int u = 0; u < DPL; ++u) sum[u] += best[u];
+            for (int u = 0; u < DPL; ++u) best[u] = -LB_INF;
+#pragma unroll 4  // four G rows per scalar-load wait
+            for (int v = 0; v < nV; ++v, g += NX) {
+                double a[NX];
+#pragma unroll
+                for (int k = 0; k < NX; ++k) a[k] = g[k];
+#pragma unroll
+                for (int u = 0; u < DPL; ++u) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) acc = fma(a[k], d[u][k], acc);
+                    best[u] = __builtin_fmax(acc, best[u]);   // one v_max_f64 (a compare + two selects otherwise); same value for non-NaN
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < DPL; ++u) sum[u] += best[u];
+        }
     }
 #pragma unroll
     for (int u = 0; u < DPL; ++u) {

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void uqmpc_step_kernel(const CtxDev* __restric
         double* cdst = (valid && io.c) ? io.c + b * ncv : nullptr;
         if (cdst) for (int k = 0; k < ncv; ++k) cdst[k] = 0.0;
         if (valid && io.active_set) for (int a = 0; a < NZMAX; ++a) io.active_set[b * NZMAX + a] = -1;
-        unsigned ctr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned ctr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         solve_lanes<NX>(C, L, ws, valid && need[0], alpha[0], v, q[0], momh[0], s0, c0, status, iters,
                         &nact, (valid && io.active_set) ? io.active_set + b * NZMAX : nullptr, cdst, ctr, nullptr, nullptr, 0);
         if (!valid) continue;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
     const int nz = C->nz, nu = C->nu, K = a.steps;
     double* ws = ws_base + wave * ws_doubles(nz);
     const SamplerDev* S = &smp;
-    unsigned ctr[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // wave-uniform work counters (lbmpc_mc_counters)
+    unsigned ctr[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // wave-uniform work counters (lbmpc_mc_counters)
 #ifdef LBMPC_PROFILE
     long long prof[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     PROF_T(pk0);
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
         }
     }
     if (lane == 0 && a.counters)
-        for (int i = 0; i < 10; ++i) atomicAdd(a.counters + i, (unsigned long long)ctr[i]);
+        for (int i = 0; i < 11; ++i) atomicAdd(a.counters + i, (unsigned long long)ctr[i]);
 #ifdef LBMPC_PROFILE
     PROF_T(pk1);
     prof[6] = pk1 - pk0;

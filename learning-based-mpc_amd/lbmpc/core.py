@@ -219,7 +219,7 @@ class Context:
         buf = (C.c_uint64 * 12)()
         _chk(self.lib.lbmpc_mc_counters(self.handle, buf), "lbmpc_mc_counters")
         names = ["filter_wave_steps", "wave_steps", "qp_solves", "solver_rounds", "solver_trips", "pivot_scans", "h_passes",
-                 "lane_trips", "lane_scans", "row_solver_qps"]
+                 "lane_trips", "lane_scans", "row_solver_qps", "lane_scan_qps"]
         return {n: int(buf[i]) for i, n in enumerate(names)}
 
     def mc_run(self, sampler, trials, steps, card_I0, seed, x0, acc_bound, distance_error, trial0=0, traj_trials=0,
