@@ -129,13 +129,18 @@ __device__ __forceinline__ void wave_argmin(double& v, int& idx) {
 }
 
 // ---- RNG: Philox4x32-10, bit-identical to oracle/lbmpc_oracle.c ------------------------------
+#ifndef PHILOX_DIAG_ROUNDS
+#define PHILOX_DIAG_ROUNDS 10
+#endif
 __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < PHILOX_DIAG_ROUNDS; ++r) {
         // one 32x32->64 product per multiplier (v_mad_u64_u32) instead of separate mul_hi / mul_lo
         const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        // three-input xor in one v_bitop3_b32 (truth table 0x96) instead of two v_xor_b32
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c[1], k0, 0x96);
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c[3], k1, 0x96);
         c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;

@@ -10,13 +10,96 @@ namespace lbmpc {
 // the form the information set uses (InitialSetComputation.m:51-52).  The draws depend on (seed, trial, step, attempt)
 // only, not on the closed-loop state, so they are produced ahead of the closed loop, one trial per lane, step by step:
 // the wave's stores of a step are one contiguous 64*nx*8-byte run of the step-major layout.  A wave repeats a draw
-// until its last lane has accepted (sample_polytope): free with the tight proposal boxes (lbmpc_sampler.EV_U / LV_U:
-// acceptance ~1), a few extra attempts per draw with loose axis-aligned ones.  grid.y splits the steps into equal
-// segments (more waves in flight).  3 Philox blocks per trial-step.
-template <int NX>
-__global__ __launch_bounds__(256) void mc_sample_kernel(SamplerDev smp, int64_t chunk_n, int64_t trial_first, int K,
-                                                        uint64_t seed, int max_attempts, double* __restrict__ xi,
-                                                        int* __restrict__ xi_status) {
+// until its last lane has accepted: free with the tight proposal boxes (lbmpc_sampler.EV_U / LV_U: acceptance ~1), a
+// few extra attempts per draw with loose axis-aligned ones.  grid.y splits the steps into equal segments (more waves
+// in flight).  3 Philox blocks per trial-step.
+//
+// Measured on C4: neither the Philox rounds (2 instead of 10: -3 %) nor the stores (-6 %) bound this kernel; the
+// control flow around them did (row loops, divergent attempt bodies, the two proposal forms: scalar-unit and branch
+// instructions, shared by the four SIMDs of a CU).  Hence: the descriptor is read from LDS as broadcasts (by value it
+// lived in SGPRs that spilled to vector lanes), rows are tested four at a time (the descriptor pads them with rows
+// 0.x <= inf), every lane evaluates every attempt and a select keeps the accepted point (no divergent body), the
+// proposal form is a template parameter and the ten round keys of the seed are computed once.
+struct PhiloxKeys { uint32_t k0[10], k1[10]; };
+__device__ __forceinline__ void philox_keys(uint64_t seed, PhiloxKeys& K) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) { K.k0[r] = k0; K.k1[r] = k1; k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+}
+// philox4x32_10 (common.hpp) with the key schedule precomputed: same words
+__device__ __forceinline__ void philox4x32_10_keys(uint32_t c[4], const PhiloxKeys& K) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c[1], K.k0[r], 0x96);
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c[3], K.k1[r], 0x96);
+        c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
+    }
+}
+// sample_polytope (common.hpp) in the form described above: same draws, same arithmetic, same accepted point
+template <int NX, bool HASU>
+__device__ __forceinline__ bool sample_polytope_rows4(const double* XA, const double* Xb, int nr /* by value: diag may zero it */, const double* lo,
+                                                      const double* hi, const double* U, const PhiloxKeys& K,
+                                                      uint64_t trial, uint32_t index, uint32_t purpose, int max_attempts,
+                                                      double* x) {
+    bool done = false;
+    for (int a = 0; a < max_attempts; ++a) {
+        uint32_t c[4] = {(uint32_t)trial, (uint32_t)(trial >> 32), index, (purpose << 28) | ((uint32_t)a << 4)};
+        philox4x32_10_keys(c, K);
+#ifdef SAMPLE_DIAG_DOUBLE_PHILOX
+        philox4x32_10_keys(c, K);
+#endif
+        double t[NX], xt[NX];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) t[k] = lo[k] + (hi[k] - lo[k]) * u01(c[k]);
+        if (HASU) {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) {
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) acc = fma(U[k * NX + i], t[i], acc);
+                xt[k] = acc;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) xt[k] = t[k];
+        }
+        bool ok = true;
+#ifdef SAMPLE_DIAG_NOROWS
+        nr = 0;
+#endif
+        for (int r = 0; r < nr; r += 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < NX; ++k) acc = fma(XA[(r + j) * NX + k], xt[k], acc);
+                ok = ok && (acc <= Xb[r + j]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NX; ++k) x[k] = done ? x[k] : xt[k];
+        done = done || ok;
+        if (__builtin_amdgcn_ballot_w64(!done) == 0) break;  // every lane accepted
+    }
+    return !done;
+}
+
+#ifndef SAMPLE_MINWAVES
+#define SAMPLE_MINWAVES 1
+#endif
+template <int NX, bool LVU, bool EVU>
+__global__ __launch_bounds__(256, SAMPLE_MINWAVES) void mc_sample_kernel(const SamplerDev* __restrict__ smp_g, int64_t chunk_n,
+                                                        int64_t trial_first, int K, uint64_t seed, int max_attempts,
+                                                        double* __restrict__ xi, int* __restrict__ xi_status) {
+    __shared__ SamplerDev smp;
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(smp_g);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&smp);
+        for (int i = threadIdx.x; i < (int)(sizeof(SamplerDev) / 4); i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+    }
     const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = l < chunk_n;
     const int64_t cl = valid ? l : chunk_n - 1;   // idle lanes of the last wave repeat the last trial (no stores)
@@ -24,15 +107,38 @@ __global__ __launch_bounds__(256) void mc_sample_kernel(SamplerDev smp, int64_t 
     const int seg = (K + (int)gridDim.y - 1) / (int)gridDim.y;
     const int kbeg = (int)blockIdx.y * seg < K ? (int)blockIdx.y * seg : K;
     const int kend = kbeg + seg < K ? kbeg + seg : K;
+    PhiloxKeys keys;
+    philox_keys(seed, keys);
+    const int nu = smp.nu, nLV = smp.nLV, nEV = smp.nEV;
     bool cap = false;
     for (int k = kbeg; k < kend; ++k) {
         double lv[NX], ev[NX], Bul[NX];
-        if (smp.LV_hasU) cap |= sample_polytope<NX>(smp.LV_A, smp.LV_b, smp.nLV, smp.LV_lo, smp.LV_hi, smp.LV_U, seed, tid, (uint32_t)k, P_ST_LV, max_attempts, lv);
-        else cap |= sample_polytope<NX>(smp.LV_A, smp.LV_b, smp.nLV, smp.LV_lo, smp.LV_hi, nullptr, seed, tid, (uint32_t)k, P_ST_LV, max_attempts, lv);
-        sample_Bu_lv<NX>(&smp, seed, tid, (uint32_t)k, P_ST_U, Bul);
-        if (smp.EV_hasU) cap |= sample_polytope<NX>(smp.EV_A, smp.EV_b, smp.nEV, smp.EV_lo, smp.EV_hi, smp.EV_U, seed, tid, (uint32_t)k, P_ST_EV, max_attempts, ev);
-        else cap |= sample_polytope<NX>(smp.EV_A, smp.EV_b, smp.nEV, smp.EV_lo, smp.EV_hi, nullptr, seed, tid, (uint32_t)k, P_ST_EV, max_attempts, ev);
+        // read where used: without the laundered offset the compiler keeps the whole descriptor in ~150 vector registers
+        int off = 0;
+        asm volatile("" : "+v"(off));
+        const SamplerDev* S = reinterpret_cast<const SamplerDev*>(reinterpret_cast<const char*>(&smp) + off);
+        cap |= sample_polytope_rows4<NX, LVU>(S->LV_A, S->LV_b, nLV, S->LV_lo, S->LV_hi, S->LV_U, keys, tid, (uint32_t)k, P_ST_LV, max_attempts, lv);
+        {   // sample_Bu_lv (common.hpp)
+            uint32_t c[4] = {(uint32_t)tid, (uint32_t)(tid >> 32), (uint32_t)k, ((uint32_t)P_ST_U << 28)};
+            philox4x32_10_keys(c, keys);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) Bul[i] = 0.0;
+#pragma unroll
+            for (int j = 0; j < LBMPC_MAX_NU; ++j)
+                if (j < nu) {
+                    const double uj = (S->max_u[j] - S->min_u[j]) * u01(c[j]) + S->min_u[j];
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) Bul[i] = fma(S->B[i * nu + j], uj, Bul[i]);
+                }
+        }
+        asm volatile("" : "+v"(off));
+        S = reinterpret_cast<const SamplerDev*>(reinterpret_cast<const char*>(&smp) + off);
+        cap |= sample_polytope_rows4<NX, EVU>(S->EV_A, S->EV_b, nEV, S->EV_lo, S->EV_hi, S->EV_U, keys, tid, (uint32_t)k, P_ST_EV, max_attempts, ev);
+#ifdef SAMPLE_DIAG_NOSTORE
+        if (valid && (ev[0] == 123.456 || k == kend - 1)) {
+#else
         if (valid) {
+#endif
             double* dst = xi + xi_index<NX>(cl, k, chunk_n);
 #pragma unroll
             for (int i = 0; i < NX; ++i) dst[i] = (ev[i] - lv[i]) - Bul[i];
@@ -243,14 +349,22 @@ static int allow_lds_steady(Kern k, size_t bytes) {
     return 0;
 }
 
-int launch_mc_sample(int nx, dim3 sg, dim3 sb, hipStream_t st, const SamplerDev& sd, int64_t cn, int64_t trial_first, int K,
-                     uint64_t seed, int max_attempts, double* xi, int* xi_status) {
+int launch_mc_sample(int nx, int lv_hasU, int ev_hasU, dim3 sg, dim3 sb, hipStream_t st, const SamplerDev* sd, int64_t cn,
+                     int64_t trial_first, int K, uint64_t seed, int max_attempts, double* xi, int* xi_status) {
+#define LS(NXV, L, E) hipLaunchKernelGGL((mc_sample_kernel<NXV, L, E>), sg, sb, 0, st, sd, cn, trial_first, K, seed, max_attempts, xi, xi_status)
+#define LS_NX(NXV)                                           \
+    do {                                                     \
+        if (lv_hasU) { if (ev_hasU) LS(NXV, true, true); else LS(NXV, true, false); } \
+        else { if (ev_hasU) LS(NXV, false, true); else LS(NXV, false, false); }       \
+    } while (0)
     switch (nx) {
-        case 1: hipLaunchKernelGGL((mc_sample_kernel<1>), sg, sb, 0, st, sd, cn, trial_first, K, seed, max_attempts, xi, xi_status); break;
-        case 2: hipLaunchKernelGGL((mc_sample_kernel<2>), sg, sb, 0, st, sd, cn, trial_first, K, seed, max_attempts, xi, xi_status); break;
-        case 3: hipLaunchKernelGGL((mc_sample_kernel<3>), sg, sb, 0, st, sd, cn, trial_first, K, seed, max_attempts, xi, xi_status); break;
-        default: hipLaunchKernelGGL((mc_sample_kernel<4>), sg, sb, 0, st, sd, cn, trial_first, K, seed, max_attempts, xi, xi_status); break;
+        case 1: LS_NX(1); break;
+        case 2: LS_NX(2); break;
+        case 3: LS_NX(3); break;
+        default: LS_NX(4); break;
     }
+#undef LS_NX
+#undef LS
     LB_HIP(hipGetLastError());
     return 0;
 }

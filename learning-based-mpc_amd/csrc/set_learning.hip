@@ -349,9 +349,37 @@ int pack_sampler(const lbmpc_sampler* s, SamplerDev* o) {
         !s->B || !s->min_u_LV || !s->max_u_LV) { set_error("lbmpc_sampler: null field"); return LBMPC_ERR_ARG; }
     if (s->nx < 1 || s->nu < 1 || s->nEV < 1 || s->nLV < 1) { set_error("lbmpc_sampler: bad size"); return LBMPC_ERR_ARG; }
     if (s->nx > LBMPC_MAX_NX || s->nu > LBMPC_MAX_NU || s->nEV > LBMPC_MAX_NXI || s->nLV > LBMPC_MAX_NXI) { set_error("lbmpc_sampler: dimension limit"); return LBMPC_ERR_DIM; }
+    *o = SamplerDev{};
+    // rows beyond nEV / nLV read 0.x <= inf: kernels that test rows four at a time need no tail
+    for (int r = 0; r < LBMPC_MAX_NXI; ++r) { o->EV_b[r] = INFINITY; o->LV_b[r] = INFINITY; }
     o->nx = s->nx; o->nu = s->nu; o->nEV = s->nEV; o->nLV = s->nLV;
-    for (int r = 0; r < s->nEV; ++r) { for (int k = 0; k < s->nx; ++k) o->EV_A[r * s->nx + k] = s->EV_A[r + (size_t)s->nEV * k]; o->EV_b[r] = s->EV_b[r]; }
-    for (int r = 0; r < s->nLV; ++r) { for (int k = 0; k < s->nx; ++k) o->LV_A[r * s->nx + k] = s->LV_A[r + (size_t)s->nLV * k]; o->LV_b[r] = s->LV_b[r]; }
+    // Rows that no proposal can violate are left out (they are most of the rows when the proposal box hugs the
+    // polytope: all of them for a cuboid in its own axes).  Proposals are t = lo + (hi-lo) u with u = (w + 1/2) 2^-32,
+    // so they stay half a granule inside the box: a row whose maximum over that inset box, plus a bound on the rounding
+    // of the evaluated a.x, is <= b holds for every candidate, and dropping it changes no accept/reject decision
+    // (the oracle evaluates all rows; streams stay bit-identical).
+    auto keep_rows = [&](const double* A, const double* b, int nr, const double* lo, const double* hi, const double* U,
+                         double* Ao, double* bo) -> int {
+        const int nx = s->nx;
+        int nk = 0;
+        for (int r = 0; r < nr; ++r) {
+            double hmax = 0.0, mag = std::fabs(b[r]);
+            for (int i = 0; i < nx; ++i) {   // g_i = a . (column i of U): the row in proposal coordinates
+                double g = 0.0;
+                for (int k = 0; k < nx; ++k) g += A[r + (size_t)nr * k] * (U ? U[k + (size_t)nx * i] : (k == i ? 1.0 : 0.0));
+                const double w = hi[i] - lo[i], inset = 0x1.0p-33 * w;
+                hmax += g > 0.0 ? g * (hi[i] - inset) : g * (lo[i] + inset);
+                mag += std::fabs(g) * (std::fabs(lo[i]) > std::fabs(hi[i]) ? std::fabs(lo[i]) : std::fabs(hi[i]));
+            }
+            if (std::isfinite(hmax) && hmax + 1e-13 * mag <= b[r]) continue;   // never violated
+            for (int k = 0; k < nx; ++k) Ao[nk * nx + k] = A[r + (size_t)nr * k];
+            bo[nk] = b[r];
+            ++nk;
+        }
+        return nk;
+    };
+    o->nEV = keep_rows(s->EV_A, s->EV_b, s->nEV, s->EV_lo, s->EV_hi, s->EV_U, o->EV_A, o->EV_b);
+    o->nLV = keep_rows(s->LV_A, s->LV_b, s->nLV, s->LV_lo, s->LV_hi, s->LV_U, o->LV_A, o->LV_b);
     for (int k = 0; k < s->nx; ++k) { o->EV_lo[k] = s->EV_lo[k]; o->EV_hi[k] = s->EV_hi[k]; o->LV_lo[k] = s->LV_lo[k]; o->LV_hi[k] = s->LV_hi[k]; }
     for (int i = 0; i < s->nx; ++i) for (int j = 0; j < s->nu; ++j) o->B[i * s->nu + j] = s->B[i + (size_t)s->nx * j];
     for (int j = 0; j < s->nu; ++j) { o->min_u[j] = s->min_u_LV[j]; o->max_u[j] = s->max_u_LV[j]; }

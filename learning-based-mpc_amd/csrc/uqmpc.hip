@@ -655,6 +655,7 @@ extern "C" void lbmpc_destroy(lbmpc_ctx* c) {
     if (c->xi_status) (void)hipFree(c->xi_status);
     if (c->counters) (void)hipFree(c->counters);
     if (c->park) (void)hipFree(c->park);
+    if (c->smp_d) (void)hipFree(c->smp_d);
     if (c->hint) (void)hipFree(c->hint);
     if (c->st_d) (void)hipFree(c->st_d);
     if (c->st_i) (void)hipFree(c->st_i);
@@ -855,6 +856,8 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
     if (int rc = pack_sampler(smp, &sd)) return rc;
     if (sd.nx != c->h.nx || sd.nu != c->h.nu) { set_error("lbmpc_mc_run: sampler dims differ from the controller's"); return LBMPC_ERR_ARG; }
     if (cfg->trials == 0) return 0;
+    if (!c->smp_d) LB_HIP(hipMalloc((void**)&c->smp_d, sizeof(SamplerDev)));
+    LB_HIP(hipMemcpyAsync(c->smp_d, &sd, sizeof(SamplerDev), hipMemcpyHostToDevice, (hipStream_t)stream));   // pageable source: staged before the call returns
     McArgs a;
     a.trials = cfg->trials; a.trial0 = cfg->trial0; a.steps = cfg->steps; a.card_I0 = cfg->card_I0; a.seed = cfg->seed;
     for (int k = 0; k < LBMPC_MAX_NX; ++k) a.x0[k] = k < c->h.nx ? cfg->x0[k] : 0.0;
@@ -942,7 +945,7 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
             segs = segs < 1 ? 1 : (segs > 64 ? 64 : segs);
             if (segs > cfg->steps) segs = cfg->steps;
             dim3 sg((unsigned)sblocks, (unsigned)segs), sb(256);
-            if (int rc = launch_mc_sample(c->h.nx, sg, sb, st, sd, cn, cfg->trial0 + c0, cfg->steps, cfg->seed, cfg->sampler_max_attempts, c->xi, c->xi_status)) return rc;
+            if (int rc = launch_mc_sample(c->h.nx, sd.LV_hasU, sd.EV_hasU, sg, sb, st, c->smp_d, cn, cfg->trial0 + c0, cfg->steps, cfg->seed, cfg->sampler_max_attempts, c->xi, c->xi_status)) return rc;
         }
         int64_t blocks = (cn + per_block - 1) / per_block;
         const int64_t resident = 256 * (int64_t)(LDS_LIMIT / lds > 4 ? 4 : (LDS_LIMIT / lds < 1 ? 1 : LDS_LIMIT / lds));

@@ -59,6 +59,7 @@ struct lbmpc_ctx {
     double* st_d = nullptr;                  // trial state handed between step segments: (3 nx + 1) doubles ...
     int* st_i = nullptr;                     // ... and 5 ints per chunk trial
     size_t st_n = 0;
+    lbmpc::SamplerDev* smp_d = nullptr;      // device copy of the sampler of the running lbmpc_mc_run (mc_sample_kernel stages it into LDS)
     double* park = nullptr;                  // state parked during solves, PARK_SLOTS doubles per grid thread
     size_t park_bytes = 0;
 };
@@ -414,7 +415,7 @@ __host__ inline size_t xi_bytes_for(int nx, int K, int64_t chunk_n) {
 }
 
 // launch wrappers of the kernels in mc_steady.hip
-int launch_mc_sample(int nx, dim3 grid, dim3 block, hipStream_t st, const SamplerDev& sd, int64_t chunk_n, int64_t trial_first,
+int launch_mc_sample(int nx, int lv_hasU, int ev_hasU, dim3 grid, dim3 block, hipStream_t st, const SamplerDev* sd_dev, int64_t chunk_n, int64_t trial_first,
                      int K, uint64_t seed, int max_attempts, double* xi, int* xi_status);
 int launch_mc_steady(const lbmpc_ctx* c, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const McArgs& a);
 
