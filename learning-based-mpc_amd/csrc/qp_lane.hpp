@@ -25,27 +25,26 @@ __device__ __forceinline__ void scan_S_lanes(const CtxDev* __restrict__ C, const
     constexpr int RLc = NX + 1;
     const int lane = lane_id();
     double ea[4], ee[4][NX], best[4];
-    int bj[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int sl = src[g] < 0 ? 0 : src[g];
         ea[g] = readlane_f64(alpha, sl);
 #pragma unroll
         for (int k = 0; k < NX; ++k) ee[g][k] = readlane_f64(e[k], sl);
-        best[g] = -QP_TOL_VIOL; bj[g] = 0x7fffffff;
+        best[g] = -QP_TOL_VIOL;
     }
     const int nch = C->nSp >> 6;  // even: nSp is a multiple of 128; pad rows are never violated
     const double* base = L.Srow + lane * RLc;
     double A[RLc], B[RLc];
-    auto eval = [&](const double* cf, int m) {
+    // Pass 1 keeps the running minimum only (one v_min_f64 per row and QP; carrying the row index along costs a compare
+    // and three selects more).  The index comes from pass 2 below.
+    auto eval = [&](const double* cf) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             double acc = ea[g] * cf[0];
 #pragma unroll
             for (int k = 0; k < NX; ++k) acc = fma(cf[1 + k], ee[g][k], acc);
-            const bool ok = acc < best[g];
-            best[g] = ok ? acc : best[g];
-            bj[g] = ok ? lane + 64 * m : bj[g];
+            best[g] = __builtin_fmin(acc, best[g]);
         }
     };
 #pragma unroll
@@ -55,17 +54,36 @@ __device__ __forceinline__ void scan_S_lanes(const CtxDev* __restrict__ C, const
 #pragma unroll
         for (int k = 0; k < RLc; ++k) B[k] = pb[k];
         __builtin_amdgcn_sched_barrier(0);
-        eval(A, m);
+        eval(A);
         const double* pa = base + (m + 2 < nch ? m + 2 : 0) * 64 * RLc;
 #pragma unroll
         for (int k = 0; k < RLc; ++k) A[k] = pa[k];
         __builtin_amdgcn_sched_barrier(0);
-        eval(B, m + 1);
+        eval(B);
     }
+    // Pass 2: the lowest row whose slack equals the wave minimum.  A lane that holds the minimum owns rows
+    // lane0 + 64 m; lane m re-evaluates row lane0 + 64 m (same operations, same bits) and the lowest hit is that
+    // lane's first row at the minimum; over the lanes that hold it (one, barring exact ties) the lowest row wins.
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        wave_argmin(best[g], bj[g]);
-        best_out[g] = best[g]; bj_out[g] = bj[g];
+        const double bmin = wave_min(best[g]);
+        int jmin = 0x7fffffff;
+        if (bmin < -QP_TOL_VIOL) {
+            uint64_t holders = __builtin_amdgcn_ballot_w64(best[g] == bmin);
+            while (holders != 0) {
+                const int l0 = (int)__builtin_ctzll(holders);
+                holders &= holders - 1;
+                const int m = lane < nch ? lane : nch - 1;
+                const double* row = L.Srow + (l0 + 64 * m) * RLc;
+                double acc = ea[g] * row[0];
+#pragma unroll
+                for (int k = 0; k < NX; ++k) acc = fma(row[1 + k], ee[g][k], acc);
+                const uint64_t hit = __builtin_amdgcn_ballot_w64(lane < nch && acc == bmin);
+                const int j = l0 + 64 * (int)__builtin_ctzll(hit | (1ull << 63));
+                jmin = (hit != 0 && j < jmin) ? j : jmin;
+            }
+        }
+        best_out[g] = bmin; bj_out[g] = jmin;
     }
 }
 
@@ -77,7 +95,7 @@ template <int NX>
 __device__ __forceinline__ void lane_qp_solve(const CtxDev* __restrict__ C, const LdsView& L, bool need, double alpha,
                                               const double* q, double min_omh, int* hint_rows /* this lane's 16 slots or null */,
                                               int* hint_n, double* z, int& status, int& iters, int& nact, int* act,
-                                              bool& fallback, unsigned* ctr) {
+                                              bool& fallback, unsigned* ctr, long long* prof = nullptr) {
     const int lane = lane_id();
     const int nS = C->nS, nz = C->nz;
     bool done = !need, have_p = false;
@@ -113,6 +131,11 @@ __device__ __forceinline__ void lane_qp_solve(const CtxDev* __restrict__ C, cons
     bool pending = false;   // this lane waits for a full scan (its z does not move meanwhile)
     while (__builtin_amdgcn_ballot_w64(!done) != 0) {
         ctr[0] += 1;
+#ifdef LBMPC_PROFILE
+        const long long pt0 = clock64();
+        long long pscan = 0;
+        if (prof) prof[4] += 1;
+#endif
         // ---- Step 1: a violated row at the current z for the lanes without a pivot ----
         // Candidates are evaluated by the lane itself; a lane that needs the full scan waits until four such lanes can
         // share one pass over the rows (or until no other lane of the wave has a step 2 to do): a pass costs the same
@@ -174,7 +197,14 @@ __device__ __forceinline__ void lane_qp_solve(const CtxDev* __restrict__ C, cons
                     }
                     double fb[4];
                     int fj[4];
+#ifdef LBMPC_PROFILE
+                    const long long ps0 = clock64();
+#endif
                     scan_S_lanes<NX>(C, L, src, alpha, e, fb, fj);
+#ifdef LBMPC_PROFILE
+                    pscan += clock64() - ps0;
+                    if (prof) prof[5] += 1;
+#endif
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq)
                         if (lane == src[gq]) { best = fb[gq]; bj = fj[gq]; scanned = true; }
@@ -217,6 +247,10 @@ __device__ __forceinline__ void lane_qp_solve(const CtxDev* __restrict__ C, cons
                 }
             }
         }
+#ifdef LBMPC_PROFILE
+        const long long pt1 = clock64();
+        if (prof) { prof[0] += pscan; prof[2] += (pt1 - pt0) - pscan; }
+#endif
         // ---- Step 2 for every lane that has a pivot ----
         const bool act2 = !done && !pending;
         if (act2) {
@@ -326,6 +360,9 @@ __device__ __forceinline__ void lane_qp_solve(const CtxDev* __restrict__ C, cons
                 nq -= 1;
             }
         }
+#ifdef LBMPC_PROFILE
+        if (prof) prof[1] += clock64() - pt1;
+#endif
     }
     nact = nq;
     if (need && !fallback && hint_rows) {   // this solve's active set = the next step's candidates

@@ -127,7 +127,7 @@ __device__ __forceinline__ void solve_lanes(const CtxDev* __restrict__ C, const 
         double zf[NX];
         int st_f = 0, it_f = 0, na_f = 0, act_f[NX];
         lane_qp_solve<NX>(C, L, need, alpha, q, min_omh, hint_base ? hint_base + (int64_t)cl * 16 : nullptr,
-                          nhint_base ? nhint_base + cl : nullptr, zf, st_f, it_f, na_f, act_f, fb, ctr + 5);
+                          nhint_base ? nhint_base + cl : nullptr, zf, st_f, it_f, na_f, act_f, fb, ctr + 5, prof);
         if (need && !fb) {
 #pragma unroll
             for (int k = 0; k < NX; ++k) s0[k] = zf[k];
