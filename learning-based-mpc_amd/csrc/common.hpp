@@ -150,7 +150,8 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
 // One 32-bit word -> uniform in (0, 1): (w + 1/2) 2^-32, exact in fp64 (granularity 2^-32 of the box width; the
 // end points are never returned).  One Philox block therefore serves a whole proposal point (nx <= 4) or input
 // draw (nu <= 4): a trial-step costs 3 blocks (xi_LV, u_LV, xi_EV) instead of the 5 of 53-bit uniforms.
-__device__ __forceinline__ double u01(uint32_t w) { return ((double)w + 0.5) * 0x1.0p-32; }
+// (one fma: w 2^-32 + 2^-33 has 33 significant bits, so it is exact and equal to the two-operation form of the oracle)
+__device__ __forceinline__ double u01(uint32_t w) { return fma((double)w, 0x1.0p-32, 0x1.0p-33); }
 
 enum { P_I0_U = 0, P_I0_EV = 1, P_I0_LV = 2, P_ST_LV = 3, P_ST_U = 4, P_ST_EV = 5 };
 

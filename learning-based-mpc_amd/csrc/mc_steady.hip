@@ -238,6 +238,9 @@ __global__ __launch_bounds__(256, 2) void mc_steady_kernel(const CtxDev* __restr
                 changed = changed || hw[r] > bh[r];
             }
             int st = 0;
+#ifdef STEADY_DIAG_NOCHANGE
+            changed = false;
+#endif
             if (__builtin_amdgcn_ballot_w64(changed) != 0) {
                 int toff = 0;
                 asm volatile("" : "+v"(toff));   // LDS constants are read here, not hoisted into registers for the loop

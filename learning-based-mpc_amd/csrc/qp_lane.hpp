@@ -44,7 +44,8 @@ __device__ __forceinline__ void scan_S_lanes(const CtxDev* __restrict__ C, const
             double acc = ea[g] * cf[0];
 #pragma unroll
             for (int k = 0; k < NX; ++k) acc = fma(cf[1 + k], ee[g][k], acc);
-            best[g] = __builtin_fmin(acc, best[g]);
+            // v_min_f64 as written: the builtin adds a canonicalising v_max_f64 on the loop-carried operand
+            asm("v_min_f64 %0, %1, %2" : "=v"(best[g]) : "v"(acc), "v"(best[g]));
         }
     };
 #pragma unroll
