@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--sl-sets", type=int, default=8192, help="information sets per GPU in the set-learning leg")
     ap.add_argument("--sl-n", type=int, default=20000, help="samples per information set")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-trials", type=int, default=1024, help="trials of the single-thread CPU leg (x8 for the all-cores leg)")
+    ap.add_argument("--cpu-trials", type=int, default=1024, help="trials of the single-thread CPU leg (x32 for the all-cores leg)")
     ap.add_argument("--sweep-dirs", type=int, default=1000000)
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the qp_active (C1/C3/C4 transient) and the large sweep legs")
     ap.add_argument("--axis-aligned-proposal", action="store_true",
@@ -332,7 +332,7 @@ def main():
         except AttributeError:
             avail = os.cpu_count() or 1
         threads = max(1, min(avail, int(os.environ.get("OMP_NUM_THREADS", avail))))
-        ct_all = ct * min(threads, 8)
+        ct_all = ct * min(threads, 8) * 4   # ~13 s on 16 host threads: with the single-thread leg about 20 s of CPU work
         t0 = time.perf_counter()
         o2 = octx.mc_run(smp, trials=ct_all, threads=threads, **kw0)
         cdt_all = time.perf_counter() - t0

@@ -206,7 +206,12 @@ __device__ __forceinline__ void load_step_const(const CtxDev* __restrict__ C, St
 #pragma unroll
     for (int r = 0; r < 2 * NX; ++r) s.wa[r] = C->box.WA[r * NX + (r >> 1) + vz];
 #pragma unroll
-    for (int i = 0; i < NX * NX; ++i) { s.ME[i] = C->ME[i + vz]; s.A[i] = C->A[i + vz]; }
+    for (int i = 0; i < NX * NX; ++i) s.A[i] = C->A[i + vz];
+    // M_E is stored bitwise symmetric (inscribed_ellipsoid): one register per pair
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int k = i; k < NX; ++k) { const double t = C->ME[i * NX + k + vz]; s.ME[i * NX + k] = t; s.ME[k * NX + i] = t; }
 #pragma unroll
     for (int i = 0; i < NX; ++i) { s.K[i] = C->K[i + vz]; s.B[i] = C->B[i + vz]; }   // nu = 1: K row 0, B column 0
     s.bmin = C->bmin;
