@@ -202,12 +202,38 @@ __global__ __launch_bounds__(256, 2) void mc_steady_kernel(const CtxDev* __restr
     bool active = valid && a.st_i[4 * cn + c] == a.kseg0;
     const double accb = a.acc_bound, derr = a.distance_error;
     // kept between steps, functions of (alpha, v) alone
-    double bh[2 * NX], bTv[NX], momh_c, as2;
-    bool ell_ok;
+    double bh[2 * NX], bTv[NX], as2;
+    bool ell_ok, need_h;   // need_h: some 1 - h_k[r] < -tol (the H rows alone ask for the solver)
+    // bound for the tightening rows: 1 - h_k[r] >= 1 - (alpha max_r hs[r] + (1-alpha) max_r |FcT[r,:]|_1 max_k |v_k|)
+    double hs_max = -LB_INF, g1_max = 0.0;
+    for (int r = 0; r < nc; ++r) {
+        double g1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) g1 += fabs(tcon0[SL::FcT + r * NX + k]);
+        g1_max = g1 > g1_max ? g1 : g1_max;
+        hs_max = tcon0[SL::hs + r] > hs_max ? tcon0[SL::hs + r] : hs_max;
+    }
     auto refresh = [&](const double* tcon) {
-        int aomh;
         w_hat_b_regs<NX>(sc, tcon + SL::wb, alpha, v, bh);
-        tighten_set_rows<NX>(tcon + SL::T, tcon + SL::FcT, tcon + SL::hs, nc, alpha, v, bTv, momh_c, aomh);
+        const double beta = 1.0 - alpha;
+        double vmax = 0.0;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < NX; ++k) acc = fma(tcon[SL::T + i * NX + k], v[k], acc);
+            bTv[i] = beta * acc;   // as tighten_set_rows()
+            vmax = fabs(v[i]) > vmax ? fabs(v[i]) : vmax;
+        }
+        // min_r (1 - h_k[r]) only matters through its sign here: the rows are walked only when the bound cannot rule
+        // a negative value out (never in the reference configurations, where 1 - h_k stays near 0.9)
+        need_h = false;
+        if (!(1.0 - (alpha * hs_max + beta * g1_max * vmax) > 1e-6)) {
+            double bTv2[NX], momh;
+            int aomh;
+            tighten_set_rows<NX>(tcon + SL::T, tcon + SL::FcT, tcon + SL::hs, nc, alpha, v, bTv2, momh, aomh);
+            need_h = momh < -QP_TOL_VIOL;
+        }
         const double as = alpha * (1.0 - 1e-6);
         as2 = as * as;
         ell_ok = sc.hasE && alpha * 1e-6 * sc.bmin >= 1e-9;   // as in ellipsoid_outside()
@@ -272,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void mc_steady_kernel(const CtxDev* __restr
                 e2 = fma(q[0][i], ti, e2);
             }
             const bool outside = !(ell_ok && e2 <= as2) && active;
-            bool need = momh_c < -QP_TOL_VIOL;
+            bool need = need_h;
             nsteps += 1;
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(outside) != 0, 0)) {
                 bool nf[1];
