@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP library (through the C ABI) against the CPU oracle on the same seeded
 inputs, and against the reference's stored goldens.  Bars (BASELINE.json north_star): flags, statuses,
 active sets, maxima and RNG streams exact; set quantities <= 1e-9 relative; QP primal <= 1e-6."""
+import os
+
 import numpy as np
 import pytest
 
@@ -642,3 +644,19 @@ def test_mc_step_segments_with_two_trials_per_lane(core, P, smp, lean):
     for k in one:
         np.testing.assert_array_equal(one[k], two[k], err_msg=k)
     ctx.close()
+
+
+@pytest.mark.parametrize("system,oriented", [("2x2", False), ("2x2", True), ("3x3", True), ("4x4", False), ("4x4", True)])
+def test_sampler_row_pruning_keeps_the_stream(core, system, oriented):
+    """pack_sampler drops polytope rows that no proposal of the box can violate (all rows of the 4x4 cuboids in their
+    own axes, the cap rows of the 3x3 prisms, the rows on the box faces of the 2x2 trapezoids); the oracle tests every
+    row of every candidate.  The accepted samples must be the same bits."""
+    from lbmpc import params
+    Pg = params.load(os.path.join(os.path.dirname(__file__), "golden", "params_2x2.npz")) if system == "2x2" else params.load(system)
+    smp = params.sampler(Pg, oriented=oriented)
+    for N, batch, set0 in [(3000, 4, 0), (257, 3, 99)]:
+        S, m, st = core.sample_information_sets(smp, Pg["W_A"], N, batch, seed=11, set0=set0)
+        S2, m2, st2 = oracle_core.sample_information_sets(smp, Pg["W_A"], N, batch, seed=11, set0=set0)
+        np.testing.assert_array_equal(S, S2)
+        np.testing.assert_array_equal(m, m2)
+        np.testing.assert_array_equal(st, st2)

@@ -4,7 +4,8 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "learning-based-mpc_amd"))
 from lbmpc import core, params, _abi
 
-P = params.load("4x4")
+SYSTEM = os.environ.get("SYSTEM", "4x4")
+P = params.load(SYSTEM)
 ctx = core.Context(P)
 smp = params.sampler(P, oriented=True)
 trials = int(os.environ.get("TRIALS", 131072)); K = int(os.environ.get("K", 1000))
@@ -14,7 +15,7 @@ lib.lbmpc_prof_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
 for rep in range(2):
     lib.lbmpc_prof_read(buf, 1)
     t0 = time.time()
-    out = ctx.mc_run(smp, trials=trials, steps=K, card_I0=10, x0=[-12, 5, 0, 0], seed=4,
+    out = ctx.mc_run(smp, trials=trials, steps=K, card_I0=10, x0=[float(t) for t in os.environ.get("X0", "-12,5,0,0").split(",")], seed=4,
                      acc_bound=float(P["acc_bound"][0]), distance_error=float(P["distance_error"][0]))
     dt = time.time() - t0
     lib.lbmpc_prof_read(buf, 0)

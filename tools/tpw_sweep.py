@@ -7,7 +7,7 @@ from lbmpc import core, dev, params
 device = torch.device("cuda:0")
 for name, P, x0, trials, steps, card in (
         ("C1 2x2", params.load(os.path.join(ROOT, "tests", "golden", "params_2x2.npz")), [-12.0, 5.0], 65536, 50, 100),
-        ("C3 3x3", params.load("3x3"), [-12.0, 5.0, 0.0], 10000, 20, 10)):
+        ("C3 3x3 as written", params.load("3x3"), [-14.9, 14.7, 0.0], 10000, 20, 10)):
     ctx = core.Context(P)
     smp = params.sampler(P, oriented=True)
     bufs = dev.McBuffers(ctx, trials, device)
