@@ -213,6 +213,68 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         if (rc < 0) fail("lbmpc:mc_run", rc);
         mxArray* vals[] = {inf, st, aK, vK, a0, it, tx, tu, ta, ts};
         for (int i = 0; i < 10; ++i) mxSetField(plhs[0], 0, names[i], vals[i]);
+    } else if (cmd == "polytope_support") {
+        // [h, z, status] = lbmpc_mex('polytope_support', A, b, C)   A m x n, b m x nb (> 0), C n x nd; h nd x nb
+        need_args(nrhs, 4, "[h, z, status] = lbmpc_mex('polytope_support', A, b, C)");
+        const int m = rows(prhs[1]), n = cols(prhs[1]);
+        const int64_t nb = cols(prhs[2]), nd = cols(prhs[3]);
+        if (rows(prhs[2]) != m || rows(prhs[3]) != n) mexErrMsgIdAndTxt("lbmpc:polytope_support", "b must be m x nb and C n x nd");
+        plhs[0] = mxCreateDoubleMatrix(nd, nb, mxREAL);
+        mxArray* z = mxCreateDoubleMatrix(n, nd * nb, mxREAL);
+        mxArray* st = mxCreateNumericMatrix(nd, nb, mxINT32_CLASS, mxREAL);
+        int rc = lbmpc_polytope_support(dbl(prhs[1]), m, n, dbl(prhs[2]), nb, dbl(prhs[3]), nd, mxGetDoubles(plhs[0]),
+                                        mxGetDoubles(z), (int*)mxGetData(st));
+        if (rc < 0) fail("lbmpc:polytope_support", rc);
+        if (nlhs > 1) plhs[1] = z;
+        if (nlhs > 2) plhs[2] = st;
+    } else if (cmd == "polytope_redundant") {
+        // [slack, status] = lbmpc_mex('polytope_redundant', A, b)   slack(j) >= 0: row j is implied by the others
+        need_args(nrhs, 3, "[slack, status] = lbmpc_mex('polytope_redundant', A, b)");
+        const int m = rows(prhs[1]), n = cols(prhs[1]);
+        if (rows(prhs[2]) * cols(prhs[2]) != m) mexErrMsgIdAndTxt("lbmpc:polytope_redundant", "b must have one entry per row of A");
+        plhs[0] = mxCreateDoubleMatrix(m, 1, mxREAL);
+        mxArray* st = mxCreateNumericMatrix(m, 1, mxINT32_CLASS, mxREAL);
+        int rc = lbmpc_polytope_redundant(dbl(prhs[1]), m, n, dbl(prhs[2]), mxGetDoubles(plhs[0]), (int*)mxGetData(st));
+        if (rc < 0) fail("lbmpc:polytope_redundant", rc);
+        if (nlhs > 1) plhs[1] = st;
+    } else if (cmd == "scmpc_mc_run") {
+        // R = lbmpc_mex('scmpc_mc_run', p, sampler, cfg)   p: N, N_SC, A, B, Q, R, F, G (ScenarioMPC.m:30-48); cfg as 'mc_run'
+        need_args(nrhs, 4, "R = lbmpc_mex('scmpc_mc_run', p, sampler, cfg)");
+        const mxArray* ps = prhs[1];
+        lbmpc_scmpc_params p;
+        p.A = dbl(field(ps, "A")); p.B = dbl(field(ps, "B")); p.Q = dbl(field(ps, "Q")); p.R = dbl(field(ps, "R"));
+        p.F = dbl(field(ps, "F")); p.G = dbl(field(ps, "G"));
+        p.nx = rows(field(ps, "A")); p.nu = cols(field(ps, "B")); p.nc = rows(field(ps, "F"));
+        p.N = ifield(ps, "N"); p.N_SC = ifield(ps, "N_SC");
+        lbmpc_sampler smp; fill_sampler(prhs[2], &smp);
+        const mxArray* s = prhs[3];
+        lbmpc_mc_cfg cfg;
+        std::memset(&cfg, 0, sizeof cfg);
+        cfg.trials = (int64_t)mxGetScalar(field(s, "trials")); cfg.trial0 = (int64_t)mxGetScalar(field(s, "trial0"));
+        cfg.steps = ifield(s, "steps"); cfg.card_I0 = 1; cfg.seed = (uint64_t)mxGetScalar(field(s, "seed"));
+        cfg.x0 = dbl(field(s, "x0")); cfg.acc_bound = mxGetScalar(field(s, "acc_bound"));
+        cfg.distance_error = mxGetScalar(field(s, "distance_error")); cfg.sampler_max_attempts = 1000;
+        const mxArray* tt = mxGetField(s, 0, "traj_trials");
+        cfg.traj_trials = tt ? (int32_t)mxGetScalar(tt) : 0;
+        if (cfg.traj_trials > cfg.trials) cfg.traj_trials = (int32_t)cfg.trials;
+        const char* names[] = {"Infeasible_Index", "status", "qp_iters", "x_K", "State_RM_SCMPC", "Control_EV_SCMPC"};
+        plhs[0] = mxCreateStructMatrix(1, 1, 6, names);
+        const size_t R = (size_t)cfg.traj_trials, K = (size_t)cfg.steps;
+        mxArray* inf = mxCreateNumericMatrix(cfg.trials, 1, mxINT32_CLASS, mxREAL);
+        mxArray* st = mxCreateNumericMatrix(cfg.trials, 1, mxINT32_CLASS, mxREAL);
+        mxArray* it = mxCreateNumericMatrix(cfg.trials, 1, mxINT32_CLASS, mxREAL);
+        mxArray* xK = mxCreateDoubleMatrix(p.nx, cfg.trials, mxREAL);
+        mxArray* tx = mxCreateDoubleMatrix(p.nx, (K + 1) * R, mxREAL);
+        mxArray* tu = mxCreateDoubleMatrix(p.nu, K * R, mxREAL);
+        lbmpc_scmpc_out out;
+        std::memset(&out, 0, sizeof out);
+        out.infeasible = (int32_t*)mxGetData(inf); out.status = (int32_t*)mxGetData(st); out.qp_iters = (int32_t*)mxGetData(it);
+        out.x_final = mxGetDoubles(xK);
+        if (R) { out.traj_x = mxGetDoubles(tx); out.traj_u = mxGetDoubles(tu); }
+        int rc = lbmpc_scmpc_mc_run(&p, &smp, &cfg, &out);
+        if (rc < 0) fail("lbmpc:scmpc_mc_run", rc);
+        mxArray* vals[] = {inf, st, it, xK, tx, tu};
+        for (int i = 0; i < 6; ++i) mxSetField(plhs[0], 0, names[i], vals[i]);
     } else {
         mexErrMsgIdAndTxt("lbmpc:usage", "unknown command %s", cmdbuf);
     }

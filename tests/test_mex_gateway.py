@@ -206,3 +206,52 @@ def test_gateway_commands_equal_the_ctypes_path(mex):
     with pytest.raises(RuntimeError, match="unknown command"):
         mex.call(0, "frobnicate")
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gateway_geometry_and_scmpc_commands(mex):
+    """'polytope_support', 'polytope_redundant' (ComputeFeasibleRegion / minHRep LPs) and 'scmpc_mc_run' (ScenarioMPC +
+    the Case_6 loop) through mexFunction == the ctypes path"""
+    from lbmpc import core
+    core.init(0)
+    P = fixtures.params_dict()
+    smp = _abi.make_sampler(**fixtures.sampler_args(P))
+    rng = np.random.default_rng(3)
+    mex.call(0, "init", 0)
+    A, b = P["S_A"], np.ravel(P["S_b"])
+    Cd = rng.normal(size=(2, 37))
+    B2 = np.stack([b, 1.3 * b], 1)                       # two right-hand sides: m x nb
+    h, z, st = mex.call(3, "polytope_support", A, B2, Cd)
+    hr, sr, zr = core.polytope_support(A, B2.T, Cd, want_z=True)
+    np.testing.assert_array_equal(h.T, hr)
+    np.testing.assert_array_equal(st.T, sr)
+    np.testing.assert_array_equal(z.T.reshape(2, 37, 2), zr)
+    (h_only,) = mex.call(0, "polytope_support", A, b, Cd)                 # one right-hand side given as a column, nlhs = 0
+    np.testing.assert_array_equal(h_only.ravel(), hr[0])
+    with pytest.raises(RuntimeError, match="lbmpc:polytope_support"):
+        mex.call(1, "polytope_support", A, b[:-1], Cd)
+    H = P["W_true_H"]
+    rows = np.vstack([H, 2.0 * H[:2], H[3:4] * np.array([1.0, 1.0, 1.5])])   # duplicates and a pushed-out row
+    slack, st2 = mex.call(2, "polytope_redundant", rows[:, :-1], rows[:, -1])
+    s_ref, st_ref = core.polytope_redundant(rows[:, :-1], rows[:, -1])
+    np.testing.assert_array_equal(slack.ravel(), s_ref)
+    np.testing.assert_array_equal(st2.ravel(), st_ref)
+    assert slack.ravel()[-1] > 0
+    # scenario MPC closed loop
+    nx, nu, N, nc = 2, 1, 8, 4
+    pst = dict(N=N, N_SC=20, A=np.reshape(P["A"], (nx, nx)), B=np.reshape(P["B"], (nx, nu)), Q=np.eye(nx), R=0.1 * np.eye(nu),
+               F=np.reshape(P["F"], (nc, nx)), G=np.reshape(P["G"], (nc, nu)))
+    cfg = dict(trials=40, trial0=3, steps=10, seed=5, x0=np.array([-12.0, 5.0]), acc_bound=2.0, distance_error=15.0, traj_trials=3)
+    (R,) = mex.call(1, "scmpc_mc_run", pst, sampler_struct(P), cfg, raw=True)
+    keep = _abi.make_scmpc_params(nx, nu, N, nc, 20, P["A"], P["B"], np.eye(nx), 0.1 * np.eye(nu), P["F"], P["G"])
+    rc, g = _abi.scmpc_mc_run(_abi.load(), "lbmpc_", keep, smp, trials=40, trial0=3, steps=10, seed=5, x0=[-12.0, 5.0],
+                              acc_bound=2.0, distance_error=15.0, traj_trials=3)
+    assert rc == 0
+    np.testing.assert_array_equal(mex.field(R, "Infeasible_Index").ravel(), g["infeasible"])
+    np.testing.assert_array_equal(mex.field(R, "status").ravel(), g["status"])
+    np.testing.assert_array_equal(mex.field(R, "qp_iters").ravel(), g["qp_iters"])
+    np.testing.assert_array_equal(mex.field(R, "x_K").T, g["x_final"])
+    np.testing.assert_array_equal(mex.field(R, "State_RM_SCMPC").T.reshape(3, 11, 2), g["traj_x"])
+    np.testing.assert_array_equal(mex.field(R, "Control_EV_SCMPC").T.reshape(3, 10, 1), g["traj_u"])
+    with pytest.raises(RuntimeError, match="lbmpc:field"):
+        mex.call(1, "scmpc_mc_run", dict(N=8), sampler_struct(P), cfg)
