@@ -5,18 +5,19 @@
 // loops of Cases_general/Case_{3,4,5}.
 //
 // Execution model (DESIGN.md "Kernel 3"):
-//   * mc_sample_kernel (pre-pass): the step disturbances w = (xi_EV - xi_LV) - B u_LV of a trial chunk, four adjacent
-//     trials per thread, stored step-major so that both this kernel's stores and the step loop's loads are whole lines;
+//   * mc_sample_kernel (pre-pass, mc_steady.hip): the step disturbances w = (xi_EV - xi_LV) - B u_LV of a trial chunk, one
+//     trial per lane, stored step-major so that both its stores and the step loop's loads are contiguous per wave;
 //   * mc_kernel / uqmpc_step_kernel, lane per trial (T trials per lane): online set update (closed-form homothety LP),
 //     h_k in closed form, then the first pass at the unconstrained minimiser z = 0 as a conservative filter -- inscribed
 //     ellipsoid test, then a packed-fp32 scan of the S rows with a rounding margin -- so that only trials that may
 //     have a violated row reach the solver;
-//   * solver (qp_group.hpp): Goldfarb-Idnani dual active set, one QP per 16-lane DPP row, four QPs per wave; the row
-//     scan reads each LDS row once for all four QPs; the factor and the KKT vectors live in registers, one column per
-//     lane; closed-loop state is parked in HBM while the solver needs the registers;
+//   * solver: Goldfarb-Idnani dual active set.  While only S rows are active or violated the QP lives in s0: one QP
+//     per lane in registers, scans of the S rows shared four QPs to a pass (qp_lane.hpp); otherwise one QP per 16-lane
+//     DPP row, four QPs per wave, factor and KKT vectors one column per lane (qp_group.hpp); closed-loop state is
+//     parked in HBM while the solver needs the registers;
 //   * u = K x + c_0, plant update, violation flags, lane per trial again;
-//   * long horizons run in step segments: mc_kernel for the transient, mc_steady_kernel (no solver, several blocks per
-//     CU) for the steps where no trial needs a QP, and a resume launch of mc_kernel for the trials that did after all.
+//   * long horizons run in step segments: mc_kernel for the transient, mc_steady_kernel (mc_steady.hip: no solver) for
+//     the steps where no trial needs a QP, and a resume launch of mc_kernel for the trials that did after all.
 // Constants ([S_b | S_A] rows in fp64 and fp32, F_bar Psi^i rows, (2P)^-1) are staged once per block into LDS.
 #include "uqmpc_dev.hpp"
 #include "qp_group.hpp"

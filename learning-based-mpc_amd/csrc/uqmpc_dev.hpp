@@ -409,7 +409,7 @@ struct McArgs {
 
 // Layout of the pre-drawn step disturbances w = (xi_EV - xi_LV) - B u_LV: [step][chunk trial][nx] with chunk trials
 // padded to a multiple of 4.  A closed-loop step reads one contiguous 64*nx*8-byte window per wave; the pre-pass
-// writes it in full lines (4 trials per thread).
+// writes the same window (one trial per lane).
 template <int NX>
 __host__ __device__ inline int64_t xi_index(int64_t cl, int k, int64_t chunk_n) {
     const int64_t np = (chunk_n + 3) & ~(int64_t)3;
