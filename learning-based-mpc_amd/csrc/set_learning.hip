@@ -306,33 +306,111 @@ extern "C" int lbmpc_halfspace_max(const double* WA, int nW, int nx, const doubl
 namespace lbmpc {
 
 // One wave per information set; lane l draws samples l, l+64, ...  (stream (seed, set0+b), index i).
+// A sample is three draws -- u_LV (always accepted), xi_EV, xi_LV (rejection) -- and every lane walks ITS OWN sequence of
+// (sample, draw, attempt): one loop trip is one Philox block, one proposal and one membership test for every lane,
+// whatever draw the lane is at, so no lane waits for another lane's rejections (in lock step per draw a wave pays the
+// maximum attempt count of its 64 lanes, 5-6 instead of 1.7 for the trapezoids of the 2x2 system).  The three draws
+// share one code path: their boxes, bases and rows sit in LDS as three descriptors of one layout and the lane
+// addresses the one of its draw (u_LV as a "polytope" without rows whose basis is B).  Same blocks, same arithmetic
+// and same accepted values as sample_w_I0().
+struct SmpPhase {
+    double lo[LBMPC_MAX_NX], hi[LBMPC_MAX_NX], U[LBMPC_MAX_NX * LBMPC_MAX_NX];
+    double A[LBMPC_MAX_NXI * LBMPC_MAX_NX], b[LBMPC_MAX_NXI];
+    int hasU, purpose, pad0, pad1;
+};
+struct SmpPhases {
+    SmpPhase ph[3];   // 0: u_LV, 1: xi_EV, 2: xi_LV
+    int nr4, pad[3];  // rows to test, a multiple of 4 (rows beyond a polytope's own read 0.x <= inf)
+    double W[LBMPC_MAX_NW * LBMPC_MAX_NX];   // W_A rows, row-major with stride nx (by value they crowd the SGPRs)
+};
+
 template <int NX>
-__global__ __launch_bounds__(256) void sample_sets_kernel(SamplerDev smp, RowsW W, int nW,
+__global__ __launch_bounds__(256) void sample_sets_kernel(const SmpPhases* __restrict__ desc_g, int nW,
                                                           int64_t N, int64_t batch, uint64_t seed, uint64_t set0,
                                                           int max_attempts, double* __restrict__ samples_out,
                                                           double* __restrict__ m_out, int* __restrict__ status_out) {
+    __shared__ SmpPhases D;
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(desc_g);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&D);
+        for (int i = threadIdx.x; i < (int)(sizeof(SmpPhases) / 4); i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+    }
     const int lane = lane_id();
     const int64_t b = (int64_t)blockIdx.x * (blockDim.x / LB_WAVE) + (threadIdx.x / LB_WAVE);
     if (b >= batch) return;
+    const uint64_t set = set0 + (uint64_t)b;
+    const int nr4 = D.nr4;
     double m[LBMPC_MAX_NW];
 #pragma unroll
     for (int j = 0; j < LBMPC_MAX_NW; ++j) m[j] = -LB_INF;
     bool cap = false;
-    for (int64_t i = lane; i < N; i += 64) {
-        double w[NX];
-        cap |= sample_w_I0<NX>(&smp, seed, set0 + (uint64_t)b, (uint32_t)i, max_attempts, w);
-        if (samples_out) {
+    int64_t i = lane;
+    int ph = 0, att = 0;
+    bool active = i < N;
+    double bu[NX], ev[NX];
 #pragma unroll
-            for (int k = 0; k < NX; ++k) samples_out[(b * N + i) * NX + k] = w[k];
+    for (int k = 0; k < NX; ++k) { bu[k] = 0.0; ev[k] = 0.0; }
+    while (__builtin_amdgcn_ballot_w64(active) != 0) {
+        const SmpPhase* P = &D.ph[ph];
+        uint32_t c[4] = {(uint32_t)set, (uint32_t)(set >> 32), (uint32_t)i, ((uint32_t)P->purpose << 28) | ((uint32_t)att << 4)};
+        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        double t[NX], x[NX];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) t[k] = P->lo[k] + (P->hi[k] - P->lo[k]) * u01(c[k]);
+        const bool hasU = P->hasU != 0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < NX; ++q) acc = fma(P->U[k * LBMPC_MAX_NX + q], t[q], acc);
+            x[k] = hasU ? acc : t[k];
         }
+        bool ok = true;
+        for (int r = 0; r < nr4; r += 4) {
 #pragma unroll
-        for (int j = 0; j < LBMPC_MAX_NW; ++j)
-            if (j < nW) {
+            for (int j = 0; j < 4; ++j) {
                 double acc = 0.0;
 #pragma unroll
-                for (int k = 0; k < NX; ++k) acc = fma(W.a[j * NX + k], w[k], acc);
-                m[j] = acc > m[j] ? acc : m[j];
+                for (int k = 0; k < NX; ++k) acc = fma(P->A[(r + j) * LBMPC_MAX_NX + k], x[k], acc);
+                ok = ok && (acc <= P->b[r + j]);
             }
+        }
+        const bool last = att + 1 >= max_attempts;
+        const bool take = active && (ok || last);   // at the attempt cap the last candidate is kept, as sample_polytope() does
+        cap = cap || (active && !ok && last);
+        if (take && ph == 0) {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) bu[k] = x[k];
+        }
+        if (take && ph == 1) {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) ev[k] = x[k];
+        }
+        if (take && ph == 2) {
+            double w[NX];
+#pragma unroll
+            for (int k = 0; k < NX; ++k) w[k] = (ev[k] - x[k]) - bu[k];
+            if (samples_out) {
+#pragma unroll
+                for (int k = 0; k < NX; ++k) samples_out[(b * N + i) * NX + k] = w[k];
+            }
+            int woff = 0;
+            asm volatile("" : "+v"(woff));   // read here, not kept in registers for the whole loop
+            const double* Wr = D.W + woff;
+#pragma unroll
+            for (int j = 0; j < LBMPC_MAX_NW; ++j)
+                if (j < nW) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) acc = fma(Wr[j * NX + k], w[k], acc);
+                    m[j] = acc > m[j] ? acc : m[j];
+                }
+            i += 64;
+            active = i < N;
+        }
+        att = take ? 0 : att + 1;
+        ph = take ? (ph == 2 ? 0 : ph + 1) : ph;
     }
     const bool anycap = __builtin_amdgcn_ballot_w64(cap) != 0;
 #pragma unroll
@@ -342,6 +420,29 @@ __global__ __launch_bounds__(256) void sample_sets_kernel(SamplerDev smp, RowsW 
             if (lane == 0 && m_out) m_out[b * nW + j] = r;
         }
     if (lane == 0 && status_out) status_out[b] = anycap ? LBMPC_ST_SAMPLER_CAP : 0;
+}
+
+// host: the three draw descriptors of sample_sets_kernel from a packed sampler
+static void pack_phases(const SamplerDev& h, SmpPhases* o) {
+    *o = SmpPhases{};
+    const int nx = h.nx, nu = h.nu;
+    for (int p = 0; p < 3; ++p)
+        for (int r = 0; r < LBMPC_MAX_NXI; ++r) o->ph[p].b[r] = INFINITY;
+    SmpPhase& u = o->ph[0];
+    for (int j = 0; j < nu; ++j) { u.lo[j] = h.min_u[j]; u.hi[j] = h.max_u[j]; }
+    for (int k = 0; k < nx; ++k) for (int j = 0; j < nu; ++j) u.U[k * LBMPC_MAX_NX + j] = h.B[k * nu + j];
+    u.hasU = 1; u.purpose = P_I0_U;
+    auto fill = [&](SmpPhase& d, const double* A, const double* b, int nr, const double* lo, const double* hi, const double* U,
+                    int hasU, int purpose) {
+        for (int k = 0; k < nx; ++k) { d.lo[k] = lo[k]; d.hi[k] = hi[k]; }
+        for (int k = 0; k < nx; ++k) for (int q = 0; q < nx; ++q) d.U[k * LBMPC_MAX_NX + q] = U[k * nx + q];
+        for (int r = 0; r < nr; ++r) { for (int k = 0; k < nx; ++k) d.A[r * LBMPC_MAX_NX + k] = A[r * nx + k]; d.b[r] = b[r]; }
+        d.hasU = hasU; d.purpose = purpose;
+    };
+    fill(o->ph[1], h.EV_A, h.EV_b, h.nEV, h.EV_lo, h.EV_hi, h.EV_U, h.EV_hasU, P_I0_EV);
+    fill(o->ph[2], h.LV_A, h.LV_b, h.nLV, h.LV_lo, h.LV_hi, h.LV_U, h.LV_hasU, P_I0_LV);
+    const int nr = h.nEV > h.nLV ? h.nEV : h.nLV;
+    o->nr4 = (nr + 3) & ~3;
 }
 
 int pack_sampler(const lbmpc_sampler* s, SamplerDev* o) {
@@ -408,14 +509,23 @@ extern "C" int lbmpc_sample_information_sets_dev(const lbmpc_sampler* smp, const
     RowsW W;
     pack_rows(WA, nW, h.nx, &W);
     dim3 grid((unsigned)((batch + 3) / 4));
-    const SamplerDev& d = h;
+    SmpPhases hp;
+    pack_phases(h, &hp);
+    for (int i = 0; i < LBMPC_MAX_NW * LBMPC_MAX_NX; ++i) hp.W[i] = W.a[i];
+    SmpPhases* d = nullptr;   // stream-ordered: the descriptors live until the kernel that reads them has run
+    LB_HIP(hipMallocAsync((void**)&d, sizeof(SmpPhases), st));
+    LB_HIP(hipMemcpyAsync(d, &hp, sizeof(SmpPhases), hipMemcpyHostToDevice, st));   // pageable source: staged before the call returns
     switch (h.nx) {
-        case 1: hipLaunchKernelGGL(sample_sets_kernel<1>, grid, dim3(256), 0, st, d, W, nW, N, batch, seed, set0, max_attempts, samples_out_dev, m_out_dev, status_out_dev); break;
-        case 2: hipLaunchKernelGGL(sample_sets_kernel<2>, grid, dim3(256), 0, st, d, W, nW, N, batch, seed, set0, max_attempts, samples_out_dev, m_out_dev, status_out_dev); break;
-        case 3: hipLaunchKernelGGL(sample_sets_kernel<3>, grid, dim3(256), 0, st, d, W, nW, N, batch, seed, set0, max_attempts, samples_out_dev, m_out_dev, status_out_dev); break;
-        default: hipLaunchKernelGGL(sample_sets_kernel<4>, grid, dim3(256), 0, st, d, W, nW, N, batch, seed, set0, max_attempts, samples_out_dev, m_out_dev, status_out_dev); break;
+        case 1: hipLaunchKernelGGL(sample_sets_kernel<1>, grid, dim3(256), 0, st, d, nW, N, batch, seed, set0, max_attempts, samples_out_dev, m_out_dev, status_out_dev); break;
+        case 2: hipLaunchKernelGGL(sample_sets_kernel<2>, grid, dim3(256), 0, st, d, nW, N, batch, seed, set0, max_attempts, samples_out_dev, m_out_dev, status_out_dev); break;
+        case 3: hipLaunchKernelGGL(sample_sets_kernel<3>, grid, dim3(256), 0, st, d, nW, N, batch, seed, set0, max_attempts, samples_out_dev, m_out_dev, status_out_dev); break;
+        default: hipLaunchKernelGGL(sample_sets_kernel<4>, grid, dim3(256), 0, st, d, nW, N, batch, seed, set0, max_attempts, samples_out_dev, m_out_dev, status_out_dev); break;
     }
-    LB_HIP(hipGetLastError());
+    {
+        const hipError_t le = hipGetLastError();
+        (void)hipFreeAsync(d, st);
+        LB_HIP(le);
+    }
     return 0;
 }
 
