@@ -401,7 +401,7 @@ def main():
                              "generate_mode": {"kernel": "sample_sets_kernel", "ms_per_launch": gen_ms,
                                                "samples_per_s": B * N / (gen_ms * 1e-3),
                                                "write_GBps": sl_bytes / (gen_ms * 1e-3) / 1e9,
-                                               "note": "Philox + rejection sampling, VALU/int-bound (3 Philox4x32-10 blocks per sample), writes each sample once"}},
+                                               "note": "Philox + rejection sampling, VALU/int-bound (3 Philox4x32-10 blocks per sample + rejected attempts; lanes advance independently), writes each sample once"}},
             "support_sweep": sweep,
             "case_6_scmpc_comparison": case6,
             "mc_stats": {"infeasible_trials": int(infeas.sum().item()), "max_status": int(status.max().item()),

@@ -15,7 +15,7 @@ lib.lbmpc_prof_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
 for rep in range(2):
     lib.lbmpc_prof_read(buf, 1)
     t0 = time.time()
-    out = ctx.mc_run(smp, trials=trials, steps=K, card_I0=10, x0=[float(t) for t in os.environ.get("X0", "-12,5,0,0").split(",")], seed=4,
+    out = ctx.mc_run(smp, trials=trials, steps=K, card_I0=int(os.environ.get("CARD", 10)), x0=[float(t) for t in os.environ.get("X0", "-12,5,0,0").split(",")], seed=4,
                      acc_bound=float(P["acc_bound"][0]), distance_error=float(P["distance_error"][0]))
     dt = time.time() - t0
     lib.lbmpc_prof_read(buf, 0)
