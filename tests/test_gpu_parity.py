@@ -660,3 +660,28 @@ def test_sampler_row_pruning_keeps_the_stream(core, system, oriented):
         np.testing.assert_array_equal(S, S2)
         np.testing.assert_array_equal(m, m2)
         np.testing.assert_array_equal(st, st2)
+
+
+@pytest.mark.parametrize("hs_scale", [1.0, 6.0, 14.0])
+def test_steady_kernel_tightening_bound_and_row_walk(core, P, smp, hs_scale):
+    """mc_steady_kernel walks the tightening rows only when its bound cannot rule out a negative 1 - h_k.  With hs
+    scaled up the bound fails (6x: the walk runs and finds every row positive or not, depending on alpha; 14x: 1 - h_k
+    is negative and every trial is handed to the solver kernel): the steady-state path must stay bitwise equal to
+    running the same steps in mc_kernel (LBMPC_MC_LEAN=0), which evaluates the rows at every step."""
+    import os
+    Ps = dict(P)
+    Ps["hs"] = np.asarray(P["hs"]) * hs_scale
+    ctx = core.Context(Ps)
+    kw = dict(trials=200, steps=70, card_I0=10, seed=23, x0=[-1.0, 0.5], acc_bound=2.0, distance_error=15.0, traj_trials=8)
+    try:
+        os.environ["LBMPC_MC_SPLIT"] = "5"
+        os.environ["LBMPC_MC_LEAN"] = "0"
+        ref = ctx.mc_run(smp, **kw)
+        os.environ["LBMPC_MC_LEAN"] = "1"
+        got = ctx.mc_run(smp, **kw)
+    finally:
+        os.environ.pop("LBMPC_MC_SPLIT", None)
+        os.environ.pop("LBMPC_MC_LEAN", None)
+    for k in ref:
+        np.testing.assert_array_equal(ref[k], got[k], err_msg=k)
+    ctx.close()
