@@ -4,9 +4,9 @@
 // variables and N_SC*N*nc rows per step) and its loop in Cases_general/Case_6...:96-150.  With the states eliminated
 // the QP has N*nu variables; its N_SC*N*nc rows share nc*N normals (F Gamma_i + G e_i'), so only the tightest scenario
 // per normal can bind: the scenario loop is a running max (rows) and a running sum (linear cost term) over the
-// N_SC*N sampled disturbances, then one small dense QP.  One trial per lane: the scenarios of a step are drawn and
-// folded in registers (3 Philox blocks per disturbance, N_SC*N = 400 per step: this is what a step costs), the QP
-// (Goldfarb-Idnani on nc*N rows, the oracle's gi_dense) runs in the lane's private memory.  Same arithmetic as
+// N_SC*N sampled disturbances, then one small dense QP.  One trial per wave: the scenarios of a step are spread over
+// the lanes (3 Philox blocks per disturbance, N_SC*N = 400 per step: this is what a step costs), the QP
+// (Goldfarb-Idnani on nc*N rows, the oracle's gi_dense) runs in lane 0's private memory.  Same arithmetic as
 // oracle/lbmpc_oracle.c (orc_scmpc_mc_run): flags, statuses and iteration counts are compared with ==.
 #include <cmath>
 #include <cstring>
@@ -112,43 +112,78 @@ struct ScArgs {
     lbmpc_scmpc_out out;   // device pointers
 };
 
+// sample_polytope() (common.hpp) for a wave in which only some lanes draw: the others count as done from the start
+template <int NX>
+__device__ __forceinline__ bool sample_polytope_if(bool act, const double* __restrict__ XA, const double* __restrict__ Xb, int nr,
+                                                   const double* __restrict__ lo, const double* __restrict__ hi,
+                                                   const double* __restrict__ U, uint64_t seed, uint64_t trial, uint32_t index,
+                                                   uint32_t purpose, int max_attempts, double* x) {
+    bool done = !act;
+    for (int a = 0; a < max_attempts; ++a) {
+        if (!done) {
+            double u[NX], xt[NX];
+            draw_uniforms<NX>(seed, trial, index, purpose, (uint32_t)a, u);
+            proposal_point<NX>(lo, hi, U, u, xt);
+            bool ok = true;
+            for (int r = 0; r < nr; ++r) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < NX; ++k) acc = fma(XA[r * NX + k], xt[k], acc);
+                ok = ok && (acc <= Xb[r]);
+            }
+#pragma unroll
+            for (int k = 0; k < NX; ++k) x[k] = xt[k];
+            done = ok;
+        }
+        if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+    }
+    return act && !done;
+}
+
+// One trial per WAVE: the N_SC scenarios of a step are spread over the lanes (lane l propagates scenarios l, l+64, ...
+// through the N stages, 3 Philox blocks per stage), the per-normal maxima are wave reductions, the per-stage sums are
+// accumulated in scenario order (the oracle's order: lane values are fetched one by one), and lane 0 solves the QP.
+// With one trial per LANE a step was N_SC*N serial draws per lane and a 4096-trial batch filled 64 of 1024 SIMDs.
 template <int NX>
 __global__ __launch_bounds__(64) void scmpc_kernel(const ScConst* __restrict__ C, SamplerDev smp, ScArgs a) {
-    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = l < a.trials;
-    const int64_t t = valid ? l : a.trials - 1;
+    __shared__ double maxF[SC_MAXM], sum[SC_MAXN][NX], zsh[SC_MAXN];
+    __shared__ int qp_st[2];
+    const int lane = threadIdx.x;
+    const int64_t t = blockIdx.x;
     const uint64_t tid = (uint64_t)(a.trial0 + t);
     const int nu = C->nu, N = C->N, nc = C->nc, n = C->n, m = C->m, K = a.steps, NSC = C->N_SC;
     int status = 0, infeasible = 0, iters_total = 0;
-    const bool rec = valid && t < a.traj_trials;
+    const bool rec = t < a.traj_trials;
     double x[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) { x[i] = a.x0[i]; if (x[i] > a.distance_error || x[i] < -a.distance_error) infeasible = 1; }
-    if (rec && a.out.traj_x) for (int i = 0; i < NX; ++i) a.out.traj_x[(t * (K + 1)) * NX + i] = x[i];
+    if (rec && lane == 0 && a.out.traj_x) for (int i = 0; i < NX; ++i) a.out.traj_x[(t * (K + 1)) * NX + i] = x[i];
     const double* EVU = smp.EV_hasU ? smp.EV_U : nullptr;
     const double* LVU = smp.LV_hasU ? smp.LV_U : nullptr;
     for (int k = 0; k < K; ++k) {
-        double maxF[SC_MAXM], sum[SC_MAXN][NX];
-        for (int j = 0; j < m; ++j) maxF[j] = -LB_INF;
-        for (int i = 0; i < N; ++i)
-#pragma unroll
-            for (int q = 0; q < NX; ++q) sum[i][q] = 0.0;
-        for (int sc = 0; sc < NSC; ++sc) {
+        for (int j = lane; j < m; j += 64) maxF[j] = -LB_INF;
+        for (int j = lane; j < N * NX; j += 64) sum[j / NX][j % NX] = 0.0;
+        __syncthreads();
+        for (int sc0 = 0; sc0 < NSC; sc0 += 64) {
+            const int sc = sc0 + lane;
+            const bool act = sc < NSC;
+            const int nact = NSC - sc0 < 64 ? NSC - sc0 : 64;
             double phi[NX];
 #pragma unroll
             for (int q = 0; q < NX; ++q) phi[q] = x[q];
             for (int i = 0; i < N; ++i) {
-                const uint32_t idx = (uint32_t)((k * NSC + sc) * N + i);
+                const uint32_t idx = (uint32_t)((k * NSC + (act ? sc : sc0)) * N + i);
                 double ev[NX], lv[NX], Bu[NX], pn[NX];
                 sample_Bu_lv<NX>(&smp, a.seed, tid, idx, P_SC_U, Bu);
-                if (sample_polytope<NX>(smp.EV_A, smp.EV_b, smp.nEV, smp.EV_lo, smp.EV_hi, EVU, a.seed, tid, idx, P_SC_EV, a.max_attempts, ev)) status = status > LBMPC_ST_SAMPLER_CAP ? status : LBMPC_ST_SAMPLER_CAP;
-                if (sample_polytope<NX>(smp.LV_A, smp.LV_b, smp.nLV, smp.LV_lo, smp.LV_hi, LVU, a.seed, tid, idx, P_SC_LV, a.max_attempts, lv)) status = status > LBMPC_ST_SAMPLER_CAP ? status : LBMPC_ST_SAMPLER_CAP;
+                bool cap = sample_polytope_if<NX>(act, smp.EV_A, smp.EV_b, smp.nEV, smp.EV_lo, smp.EV_hi, EVU, a.seed, tid, idx, P_SC_EV, a.max_attempts, ev);
+                cap |= sample_polytope_if<NX>(act, smp.LV_A, smp.LV_b, smp.nLV, smp.LV_lo, smp.LV_hi, LVU, a.seed, tid, idx, P_SC_LV, a.max_attempts, lv);
+                if (__builtin_amdgcn_ballot_w64(cap) != 0) status = status > LBMPC_ST_SAMPLER_CAP ? status : LBMPC_ST_SAMPLER_CAP;
 #pragma unroll
                 for (int q = 0; q < NX; ++q) {
                     double acc = 0.0;
 #pragma unroll
                     for (int b = 0; b < NX; ++b) acc = fma(C->A[q * NX + b], phi[b], acc);
-                    pn[q] = acc + ((ev[q] - lv[q]) - Bu[q]);
+                    pn[q] = act ? acc + ((ev[q] - lv[q]) - Bu[q]) : 0.0;
                 }
 #pragma unroll
                 for (int q = 0; q < NX; ++q) phi[q] = pn[q];
@@ -156,33 +191,49 @@ __global__ __launch_bounds__(64) void scmpc_kernel(const ScConst* __restrict__ C
                     double f = 0.0;
 #pragma unroll
                     for (int b = 0; b < NX; ++b) f = fma(C->F[r * NX + b], phi[b], f);
-                    if (f > maxF[i * nc + r]) maxF[i * nc + r] = f;
+                    const double fm = wave_max(act ? f : -LB_INF);
+                    if (lane == 0 && fm > maxF[i * nc + r]) maxF[i * nc + r] = fm;
                 }
+                // sum over the scenarios in scenario order (bit-identical to the serial accumulation)
 #pragma unroll
-                for (int q = 0; q < NX; ++q) sum[i][q] += phi[q];
+                for (int q = 0; q < NX; ++q) {
+                    double acc = sum[i][q];
+                    for (int l2 = 0; l2 < nact; ++l2) acc += readlane_f64(phi[q], l2);
+                    if (lane == 0) sum[i][q] = acc;
+                }
             }
         }
-        double g[SC_MAXN], Uu[SC_MAXN], d[SC_MAXM], z[SC_MAXN];
-        for (int j = 0; j < n; ++j) {
-            double acc = 0.0;
-            for (int i = 0; i < N; ++i)
+        __syncthreads();
+        double Uu[SC_MAXN];
+        {
+            double g[SC_MAXN];
+            for (int j = 0; j < n; ++j) {
+                double acc = 0.0;
+                for (int i = 0; i < N; ++i)
 #pragma unroll
-                for (int q = 0; q < NX; ++q) acc = fma(C->GQ[i][j][q], sum[i][q], acc);
-            g[j] = acc;
+                    for (int q = 0; q < NX; ++q) acc = fma(C->GQ[i][j][q], sum[i][q], acc);
+                g[j] = acc;
+            }
+            for (int j = 0; j < n; ++j) { double acc = 0.0; for (int q = 0; q < n; ++q) acc = fma(C->Ginv[j * n + q], g[q], acc); Uu[j] = -2.0 * acc; }
         }
-        for (int j = 0; j < n; ++j) { double acc = 0.0; for (int q = 0; q < n; ++q) acc = fma(C->Ginv[j * n + q], g[q], acc); Uu[j] = -2.0 * acc; }
-        for (int j = 0; j < m; ++j) {
-            double acc = 0.0;
-            for (int q = 0; q < n; ++q) acc = fma(C->Cm[(size_t)j * n + q], Uu[q], acc);
-            d[j] = (1.0 - maxF[j]) - acc;
+        if (lane == 0) {
+            double d[SC_MAXM], z[SC_MAXN];
+            for (int j = 0; j < m; ++j) {
+                double acc = 0.0;
+                for (int q = 0; q < n; ++q) acc = fma(C->Cm[(size_t)j * n + q], Uu[q], acc);
+                d[j] = (1.0 - maxF[j]) - acc;
+            }
+            int it = 0;
+            qp_st[0] = gi_dense_dev(n, m, C->Cm, d, C->Ginv, z, &it);
+            qp_st[1] = it;
+            for (int j = 0; j < n; ++j) zsh[j] = z[j];
         }
-        int it = 0;
-        const int st = gi_dense_dev(n, m, C->Cm, d, C->Ginv, z, &it);
-        status = st > status ? st : status;
-        iters_total += it;
+        __syncthreads();
+        status = qp_st[0] > status ? qp_st[0] : status;
+        iters_total += qp_st[1];
         double u0[LBMPC_MAX_NU];
-        for (int j = 0; j < nu; ++j) u0[j] = z[j] + Uu[j];
-        // plant: the step disturbance of lbmpc_mc_run for this (trial, step)
+        for (int j = 0; j < nu; ++j) u0[j] = zsh[j] + Uu[j];
+        // plant: the step disturbance of lbmpc_mc_run for this (trial, step); every lane computes the same values
         double xl[NX], xe[NX], Bul[NX], Ax[NX], Bu2[NX];
         if (sample_polytope<NX>(smp.LV_A, smp.LV_b, smp.nLV, smp.LV_lo, smp.LV_hi, LVU, a.seed, tid, (uint32_t)k, P_ST_LV, a.max_attempts, xl)) status = status > LBMPC_ST_SAMPLER_CAP ? status : LBMPC_ST_SAMPLER_CAP;
         sample_Bu_lv<NX>(&smp, a.seed, tid, (uint32_t)k, P_ST_U, Bul);
@@ -200,12 +251,13 @@ __global__ __launch_bounds__(64) void scmpc_kernel(const ScConst* __restrict__ C
         for (int j = 0; j < nu; ++j) if (u0[j] > a.acc_bound || u0[j] < -a.acc_bound) infeasible = 1;
 #pragma unroll
         for (int q = 0; q < NX; ++q) if (x[q] > a.distance_error || x[q] < -a.distance_error) infeasible = 1;
-        if (rec) {
+        if (rec && lane == 0) {
             if (a.out.traj_x) for (int q = 0; q < NX; ++q) a.out.traj_x[(t * (K + 1) + k + 1) * NX + q] = x[q];
             if (a.out.traj_u) for (int j = 0; j < nu; ++j) a.out.traj_u[(t * K + k) * nu + j] = u0[j];
         }
+        __syncthreads();   // the next step re-initialises maxF / sum
     }
-    if (!valid) return;
+    if (lane != 0) return;
     if (a.out.infeasible) a.out.infeasible[t] = infeasible;
     if (a.out.status) a.out.status[t] = status;
     if (a.out.qp_iters) a.out.qp_iters[t] = iters_total;
@@ -319,7 +371,7 @@ extern "C" int lbmpc_scmpc_mc_run(const lbmpc_scmpc_params* p, const lbmpc_sampl
     for (int k = 0; k < LBMPC_MAX_NX; ++k) a.x0[k] = k < p->nx ? cfg->x0[k] : 0.0;
     a.out.infeasible = o[0].buf.as<int32_t>(); a.out.status = o[1].buf.as<int32_t>(); a.out.qp_iters = o[2].buf.as<int32_t>();
     a.out.x_final = o[3].buf.as<double>(); a.out.traj_x = o[4].buf.as<double>(); a.out.traj_u = o[5].buf.as<double>();
-    dim3 grid((unsigned)((cfg->trials + 63) / 64)), blk(64);
+    dim3 grid((unsigned)cfg->trials), blk(64);   // one trial per wave
     switch (p->nx) {
         case 1: hipLaunchKernelGGL(scmpc_kernel<1>, grid, blk, 0, nullptr, dc.as<ScConst>(), sd, a); break;
         case 2: hipLaunchKernelGGL(scmpc_kernel<2>, grid, blk, 0, nullptr, dc.as<ScConst>(), sd, a); break;
