@@ -313,7 +313,8 @@ typedef struct lbmpc_scmpc_out { /* host pointers; any may be NULL */
  * scenarios w = xi_EV - xi_LV - B u_LV (:60-68), solve the scenario QP in the N*nu inputs (states eliminated; the
  * N_SC*N*nc rows F x + G u <= 1 share nc*N normals, so only the tightest scenario per normal is kept: a max-reduction
  * over the scenarios), apply u_0, step the plant with the SAME step disturbances lbmpc_mc_run uses for these trial ids
- * (Case_6 runs both controllers against one realisation).  cfg->card_I0 is ignored.  One trial per lane. */
+ * (Case_6 runs both controllers against one realisation).  cfg->card_I0 is ignored.  One trial per wave (the scenarios
+ * of a step are spread over the lanes). */
 int lbmpc_scmpc_mc_run(const lbmpc_scmpc_params* p, const lbmpc_sampler* smp, const lbmpc_mc_cfg* cfg, lbmpc_scmpc_out* out);
 
 /* ------------------------------------------------------------------------------------------
