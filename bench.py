@@ -245,6 +245,21 @@ def main():
                                    "includes its host<->device copies"}
             cq.close()
 
+    # ---------------------------------------------------------------- offline parameter scripts
+    offline_leg = None
+    if not args.no_extra_legs and rank == 0:
+        from lbmpc import pipeline
+        ref_stats = np.load(os.path.join(ROOT, "tests", "golden", "stats.npz"))
+        offline_leg = {}
+        for nxo in (2, 3, 4):
+            pipeline.offline_parameters(nxo)                      # warm-up (first launches, LRU of the support rows)
+            t0 = time.perf_counter()
+            Po, so = pipeline.offline_parameters(nxo)
+            offline_leg[f"{nxo}x{nxo}"] = {
+                "seconds": time.perf_counter() - t0, "S_rows": int(Po["S_H"].shape[0]), "Nu": int(Po["Nu"]),
+                "reference_stored_seconds": float(np.ravel(ref_stats[f"{nxo}x{nxo}_elapsedTime"])[0]),
+                "note": "offline_parameters_computation_nxn.m end to end (sets, tube, feasible regions, Ps) through the library; "
+                        "reference: elapsedTime of its own stats_nxn.mat (MATLAB + MPT3 + IPOPT, hardware unknown)"}
     # ---------------------------------------------------------------- set learning (C2)
     P2 = params.load(os.path.join(ROOT, "tests", "golden", "params_2x2.npz"))
     smp2 = params.sampler(P2)
@@ -404,6 +419,7 @@ def main():
                                                "note": "Philox + rejection sampling, VALU/int-bound (3 Philox4x32-10 blocks per sample + rejected attempts; lanes advance independently), writes each sample once"}},
             "support_sweep": sweep,
             "case_6_scmpc_comparison": case6,
+            "offline_pipeline": offline_leg,
             "mc_stats": {"infeasible_trials": int(infeas.sum().item()), "max_status": int(status.max().item()),
                          "mean_qp_iters_per_trial": float(iters.double().mean().item())},
             "cpu_baseline": cpu,

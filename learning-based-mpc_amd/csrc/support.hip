@@ -287,7 +287,7 @@ extern "C" int lbmpc_mrpi_s_alpha(const double* A, int nx, const double* Vw, int
     if (!WA || !Wb || !Dirs || !s_out || !alpha_out || nW < 1 || ndirs < 1 || max_s < 1 || mode < 0 || mode > 2) { set_error("lbmpc_mrpi_s_alpha: bad argument"); return LBMPC_ERR_ARG; }
     if (max_s > LBMPC_MAX_S - 1) max_s = LBMPC_MAX_S - 1;
     if (int rc = check_support_args(A, nx, Vw, nV, 1)) return rc;
-    if (nW > LBMPC_MAX_NW) return LBMPC_ERR_DIM;
+    if (nW > 65536) { set_error("lbmpc_mrpi_s_alpha: nW <= 65536"); return LBMPC_ERR_DIM; }   // the rows are only directions here: no fixed-size storage
     const int tr = (mode == LBMPC_MS_RAKOVIC);
     std::vector<double> G;
     stack_G(A, nx, Vw, nV, max_s + 1, tr, G);

@@ -183,7 +183,7 @@ int orc_mrpi_s_alpha(const double* A, int nx, const double* Vw, int nV, const do
                      const double* Wb, int nW, const double* Dirs, int ndirs, double eps, int mode,
                      int max_s, int* s_out, double* alpha_out, double* Ms_out) {
     if (!A || !Vw || !WA || !Wb || !Dirs || !s_out || !alpha_out) return LBMPC_ERR_ARG;
-    if (nx > LBMPC_MAX_NX || nV > LBMPC_MAX_NV || nW > LBMPC_MAX_NW || max_s > LBMPC_MAX_S) return LBMPC_ERR_DIM;
+    if (nx > LBMPC_MAX_NX || nV > LBMPC_MAX_NV || nW > 65536 || max_s > LBMPC_MAX_S) return LBMPC_ERR_DIM;
     int tr = (mode == LBMPC_MS_RAKOVIC);
     /* G[t] for t = 0..max_s (A^t or (A^t)') */
     double* G = (double*)malloc(sizeof(double) * (size_t)(max_s + 1) * nV * nx);
