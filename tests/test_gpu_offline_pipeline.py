@@ -130,3 +130,14 @@ def test_pipeline_3x3_runs_and_prunes():
     assert np.allclose(P["K"], c["K"], atol=1e-10)
     assert np.allclose(P["hs"].ravel(), c["hs"].ravel(), rtol=0, atol=1e-9)   # F_Com rows are template directions
     assert stats["S_num_constraints"] <= stats["S_template_rows"]
+
+
+def test_pipeline_4x4_runs_with_a_many_faced_w_true():
+    """4x4: W_true (sum of two rotated 4-D cuboids and a segment) has far more than LBMPC_MAX_NW facets; the (s, alpha)
+    search takes them as directions.  K and the exact tightening equal the committed parameter set's."""
+    P, stats = pipeline.offline_parameters(4, n_template=400, n_region=100)
+    assert len(P["W_true_H"]) > 16 and P["W_true_V"].shape[1] == 4
+    c = np.load(os.path.join(os.path.dirname(core.__file__), "..", "params", "params_4x4.npz"))
+    assert np.allclose(P["K"], c["K"], atol=1e-10)
+    assert np.allclose(P["hs"].ravel(), c["hs"].ravel(), rtol=0, atol=1e-9)
+    assert int(P["Nu"]) >= 8 and stats["S_num_constraints"] <= stats["S_template_rows"]
