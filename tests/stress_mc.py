@@ -1,4 +1,4 @@
-"""GPU vs oracle closed loops over varied seeds, start states, card(I0) and proposal forms (steady-state kernel included) -- diagnostic."""
+"""GPU vs oracle closed loops over varied seeds, start states, card(I0) and proposal forms (steady-state kernel included) -- run by hand (python tests/stress_mc.py on a GPU box); it lives under tests/ because it uses the oracle."""
 import sys, os, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "learning-based-mpc_amd"))
