@@ -179,6 +179,22 @@ struct SamplerDev {
 };
 int pack_sampler(const lbmpc_sampler* s, SamplerDev* out);  // host: validate + repack
 
+// The three draws of one information-set sample as descriptors of one layout (sample_sets_kernel, set_learning.hip)
+struct SmpPhase {
+    double lo[LBMPC_MAX_NX], hi[LBMPC_MAX_NX], U[LBMPC_MAX_NX * LBMPC_MAX_NX];
+    double A[LBMPC_MAX_NXI * LBMPC_MAX_NX], b[LBMPC_MAX_NXI];
+    int hasU, purpose, pad0, pad1;
+};
+struct SmpPhases {
+    SmpPhase ph[3];   // 0: u_LV, 1: xi_EV, 2: xi_LV
+    int nr4, pad[3];  // rows to test, a multiple of 4 (rows beyond a polytope's own read 0.x <= inf)
+    double W[LBMPC_MAX_NW * LBMPC_MAX_NX];   // W_A rows, row-major with stride nx (by value they crowd the SGPRs)
+};
+int pack_sample_phases(const SamplerDev& h, const double* W_rows /* nW x nx row-major */, int nW, SmpPhases* o);  // host
+// m[b, j] = max_i W_rows[j].w_{b,i} over N generated samples of information sets set0 + b (one Philox stream per set), desc on the device
+int launch_sample_sets(int nx, int nu, const SmpPhases* desc_dev, int nW, int64_t N, int64_t batch, uint64_t seed, uint64_t set0,
+                       int max_attempts, double* samples_out_dev, double* m_out_dev, int* status_out_dev, hipStream_t st);
+
 // candidate x = U t, t = lo + (hi - lo) u  (U = I when null)
 template <int NX>
 __device__ __forceinline__ void proposal_point(const double* __restrict__ lo, const double* __restrict__ hi,

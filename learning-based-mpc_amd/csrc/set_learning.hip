@@ -313,21 +313,14 @@ namespace lbmpc {
 // share one code path: their boxes, bases and rows sit in LDS as three descriptors of one layout and the lane
 // addresses the one of its draw (u_LV as a "polytope" without rows whose basis is B).  Same blocks, same arithmetic
 // and same accepted values as sample_w_I0().
-struct SmpPhase {
-    double lo[LBMPC_MAX_NX], hi[LBMPC_MAX_NX], U[LBMPC_MAX_NX * LBMPC_MAX_NX];
-    double A[LBMPC_MAX_NXI * LBMPC_MAX_NX], b[LBMPC_MAX_NXI];
-    int hasU, purpose, pad0, pad1;
-};
-struct SmpPhases {
-    SmpPhase ph[3];   // 0: u_LV, 1: xi_EV, 2: xi_LV
-    int nr4, pad[3];  // rows to test, a multiple of 4 (rows beyond a polytope's own read 0.x <= inf)
-    double W[LBMPC_MAX_NW * LBMPC_MAX_NX];   // W_A rows, row-major with stride nx (by value they crowd the SGPRs)
-};
-
-template <int NX>
+// lps lanes per information set (a power of two, 64 / lps sets per wave): 64 for large N; small information sets
+// (the card(I0) = 10 ... 100 of the closed-loop Monte-Carlo, one set per trial) take fewer, so that the lanes of a
+// wave are busy and one wave learns several sets.  NT: length of the proposal vector t (NX, or LBMPC_MAX_NU when the
+// input draw has more components than the state: nu > nx).
+template <int NX, int NT>
 __global__ __launch_bounds__(256) void sample_sets_kernel(const SmpPhases* __restrict__ desc_g, int nW,
                                                           int64_t N, int64_t batch, uint64_t seed, uint64_t set0,
-                                                          int max_attempts, double* __restrict__ samples_out,
+                                                          int max_attempts, int lps, double* __restrict__ samples_out,
                                                           double* __restrict__ m_out, int* __restrict__ status_out) {
     __shared__ SmpPhases D;
     {
@@ -337,17 +330,19 @@ __global__ __launch_bounds__(256) void sample_sets_kernel(const SmpPhases* __res
         __syncthreads();
     }
     const int lane = lane_id();
-    const int64_t b = (int64_t)blockIdx.x * (blockDim.x / LB_WAVE) + (threadIdx.x / LB_WAVE);
-    if (b >= batch) return;
+    const int spw = LB_WAVE / lps;   // sets per wave
+    const int64_t wv = (int64_t)blockIdx.x * (blockDim.x / LB_WAVE) + (threadIdx.x / LB_WAVE);
+    if (wv * spw >= batch) return;
+    const int64_t b = wv * spw + lane / lps;
     const uint64_t set = set0 + (uint64_t)b;
     const int nr4 = D.nr4;
     double m[LBMPC_MAX_NW];
 #pragma unroll
     for (int j = 0; j < LBMPC_MAX_NW; ++j) m[j] = -LB_INF;
     bool cap = false;
-    int64_t i = lane;
+    int64_t i = lane & (lps - 1);
     int ph = 0, att = 0;
-    bool active = i < N;
+    bool active = b < batch && i < N;
     double bu[NX], ev[NX];
 #pragma unroll
     for (int k = 0; k < NX; ++k) { bu[k] = 0.0; ev[k] = 0.0; }
@@ -355,15 +350,15 @@ __global__ __launch_bounds__(256) void sample_sets_kernel(const SmpPhases* __res
         const SmpPhase* P = &D.ph[ph];
         uint32_t c[4] = {(uint32_t)set, (uint32_t)(set >> 32), (uint32_t)i, ((uint32_t)P->purpose << 28) | ((uint32_t)att << 4)};
         philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-        double t[NX], x[NX];
+        double t[NT], x[NX];
 #pragma unroll
-        for (int k = 0; k < NX; ++k) t[k] = P->lo[k] + (P->hi[k] - P->lo[k]) * u01(c[k]);
+        for (int k = 0; k < NT; ++k) t[k] = P->lo[k] + (P->hi[k] - P->lo[k]) * u01(c[k]);
         const bool hasU = P->hasU != 0;
 #pragma unroll
         for (int k = 0; k < NX; ++k) {
             double acc = 0.0;
 #pragma unroll
-            for (int q = 0; q < NX; ++q) acc = fma(P->U[k * LBMPC_MAX_NX + q], t[q], acc);
+            for (int q = 0; q < NT; ++q) acc = fma(P->U[k * LBMPC_MAX_NX + q], t[q], acc);   // columns >= nx (nu) of a basis are exact zeros
             x[k] = hasU ? acc : t[k];
         }
         bool ok = true;
@@ -406,20 +401,33 @@ __global__ __launch_bounds__(256) void sample_sets_kernel(const SmpPhases* __res
                     for (int k = 0; k < NX; ++k) acc = fma(Wr[j * NX + k], w[k], acc);
                     m[j] = acc > m[j] ? acc : m[j];
                 }
-            i += 64;
+            i += lps;
             active = i < N;
         }
         att = take ? 0 : att + 1;
         ph = take ? (ph == 2 ? 0 : ph + 1) : ph;
     }
-    const bool anycap = __builtin_amdgcn_ballot_w64(cap) != 0;
+    if (lps == LB_WAVE) {
+        const bool anycap = __builtin_amdgcn_ballot_w64(cap) != 0;
 #pragma unroll
-    for (int j = 0; j < LBMPC_MAX_NW; ++j)
-        if (j < nW) {
-            double r = wave_max(m[j]);
-            if (lane == 0 && m_out) m_out[b * nW + j] = r;
-        }
-    if (lane == 0 && status_out) status_out[b] = anycap ? LBMPC_ST_SAMPLER_CAP : 0;
+        for (int j = 0; j < LBMPC_MAX_NW; ++j)
+            if (j < nW) {
+                double r = wave_max(m[j]);
+                if (lane == 0 && m_out) m_out[b * nW + j] = r;
+            }
+        if (lane == 0 && status_out) status_out[b] = anycap ? LBMPC_ST_SAMPLER_CAP : 0;
+    } else {   // several sets per wave: butterfly inside each group of lps lanes
+        int capi = cap ? 1 : 0;
+        for (int off = lps >> 1; off > 0; off >>= 1) capi |= __shfl_xor(capi, off);
+#pragma unroll
+        for (int j = 0; j < LBMPC_MAX_NW; ++j)
+            if (j < nW) {
+                double r = m[j];
+                for (int off = lps >> 1; off > 0; off >>= 1) { const double o = __shfl_xor(r, off); r = o > r ? o : r; }
+                if ((lane & (lps - 1)) == 0 && b < batch && m_out) m_out[b * nW + j] = r;
+            }
+        if ((lane & (lps - 1)) == 0 && b < batch && status_out) status_out[b] = capi ? LBMPC_ST_SAMPLER_CAP : 0;
+    }
 }
 
 // host: the three draw descriptors of sample_sets_kernel from a packed sampler
@@ -508,26 +516,48 @@ extern "C" int lbmpc_sample_information_sets_dev(const lbmpc_sampler* smp, const
     hipStream_t st = (hipStream_t)stream;
     RowsW W;
     pack_rows(WA, nW, h.nx, &W);
-    dim3 grid((unsigned)((batch + 3) / 4));
     SmpPhases hp;
     pack_phases(h, &hp);
     for (int i = 0; i < LBMPC_MAX_NW * LBMPC_MAX_NX; ++i) hp.W[i] = W.a[i];
     SmpPhases* d = nullptr;   // stream-ordered: the descriptors live until the kernel that reads them has run
     LB_HIP(hipMallocAsync((void**)&d, sizeof(SmpPhases), st));
     LB_HIP(hipMemcpyAsync(d, &hp, sizeof(SmpPhases), hipMemcpyHostToDevice, st));   // pageable source: staged before the call returns
-    switch (h.nx) {
-        case 1: hipLaunchKernelGGL(sample_sets_kernel<1>, grid, dim3(256), 0, st, d, nW, N, batch, seed, set0, max_attempts, samples_out_dev, m_out_dev, status_out_dev); break;
-        case 2: hipLaunchKernelGGL(sample_sets_kernel<2>, grid, dim3(256), 0, st, d, nW, N, batch, seed, set0, max_attempts, samples_out_dev, m_out_dev, status_out_dev); break;
-        case 3: hipLaunchKernelGGL(sample_sets_kernel<3>, grid, dim3(256), 0, st, d, nW, N, batch, seed, set0, max_attempts, samples_out_dev, m_out_dev, status_out_dev); break;
-        default: hipLaunchKernelGGL(sample_sets_kernel<4>, grid, dim3(256), 0, st, d, nW, N, batch, seed, set0, max_attempts, samples_out_dev, m_out_dev, status_out_dev); break;
+    const int rc = launch_sample_sets(h.nx, h.nu, d, nW, N, batch, seed, set0, max_attempts, samples_out_dev, m_out_dev, status_out_dev, st);
+    (void)hipFreeAsync(d, st);
+    return rc;
+}
+
+namespace lbmpc {
+// lanes per information set: the smallest power of two >= N, at most a wave (small sets share a wave)
+static int lanes_per_set(int64_t N) {
+    int lps = 4;
+    while (lps < LB_WAVE && lps < N) lps <<= 1;
+    return lps;
+}
+int launch_sample_sets(int nx, int nu, const SmpPhases* d, int nW, int64_t N, int64_t batch, uint64_t seed, uint64_t set0,
+                       int max_attempts, double* samples_out_dev, double* m_out_dev, int* status_out_dev, hipStream_t st) {
+    const int lps = lanes_per_set(N);
+    const int64_t waves = (batch + (LB_WAVE / lps) - 1) / (LB_WAVE / lps);
+    dim3 grid((unsigned)((waves + 3) / 4));
+#define LAUNCH_SS(NXV, NTV) hipLaunchKernelGGL((sample_sets_kernel<NXV, NTV>), grid, dim3(256), 0, st, d, nW, N, batch, seed, set0, max_attempts, lps, samples_out_dev, m_out_dev, status_out_dev)
+    const bool wide = nu > nx;   // the input draw has more components than the state
+    switch (nx) {
+        case 1: if (wide) LAUNCH_SS(1, LBMPC_MAX_NU); else LAUNCH_SS(1, 1); break;
+        case 2: if (wide) LAUNCH_SS(2, LBMPC_MAX_NU); else LAUNCH_SS(2, 2); break;
+        case 3: if (wide) LAUNCH_SS(3, LBMPC_MAX_NU); else LAUNCH_SS(3, 3); break;
+        default: LAUNCH_SS(4, 4); break;
     }
-    {
-        const hipError_t le = hipGetLastError();
-        (void)hipFreeAsync(d, st);
-        LB_HIP(le);
-    }
+#undef LAUNCH_SS
+    LB_HIP(hipGetLastError());
     return 0;
 }
+int pack_sample_phases(const SamplerDev& h, const double* W_rows /* nW x nx row-major */, int nW, SmpPhases* o) {
+    pack_phases(h, o);
+    for (int i = 0; i < LBMPC_MAX_NW * LBMPC_MAX_NX; ++i) o->W[i] = 0.0;
+    for (int i = 0; i < nW * h.nx; ++i) o->W[i] = W_rows[i];
+    return 0;
+}
+}  // namespace lbmpc
 
 extern "C" int lbmpc_sample_information_sets(const lbmpc_sampler* smp, const double* WA, int nW, int64_t N,
                                              int64_t batch, uint64_t seed, uint64_t set0, int max_attempts,

@@ -22,12 +22,13 @@
 #include "uqmpc_dev.hpp"
 #include "qp_group.hpp"
 #include "qp_lane.hpp"
+#include "qp_lane_gen.hpp"
 
 namespace lbmpc {
 
 // Copies the constants into LDS and returns the view; *ws_base = first per-wave solver slot.
 __device__ __forceinline__ LdsView stage_constants(const CtxDev* __restrict__ C, double* lds, double** ws_base) {
-    const int nS_RL = C->nSp * C->RL, nH_nzp = C->nH * C->nzp, nzz = C->nz * C->nz;
+    const int nS_RL = C->nSp * C->RL, nH_nzp = C->nHs * C->nzp, nzz = C->nz * C->nz;
     const int d64 = (nS_RL + nH_nzp + nzz + 1) & ~1;
     float* s32 = reinterpret_cast<float*>(lds + d64);
     for (int i = threadIdx.x; i < nS_RL; i += blockDim.x) lds[i] = C->Srow[i];
@@ -113,17 +114,22 @@ __device__ __forceinline__ void solve_flagged(const CtxDev* __restrict__ C, cons
 }
 
 // Solve the QPs of the flagged lanes: the one-QP-per-lane solver of the S-row regime first (qp_lane.hpp), then the
-// 16-lane-row solver for the lanes that left it (rows of F_bar Psi^i in play).  Same outputs as solve_flagged.
+// one-QP-per-lane solver with rows of F_bar Psi^i in play (qp_lane_gen.hpp; lgs = this wave's LDS region for glanes
+// lanes, glanes = 0: not available), then the 16-lane-row solver for what is left.  Same outputs as solve_flagged.
 // ctr: [0] QPs, [1] rounds, [2] trips, [3] scans, [4] H passes of the row solver, [5] lane-solver trips,
-// [6] lane-solver scan passes, [7] QPs that went through the row solver.
+// [6] lane-solver scan passes, [7] QPs that went through the row solver, [8] QPs served by lane-solver scans,
+// [9..13] general lane solver: trips, S scan passes, H passes, QPs served by scans, factor rebuilds, [14] its QPs.
 template <int NX>
-__device__ __forceinline__ void solve_lanes(const CtxDev* __restrict__ C, const LdsView& L, double* wws, bool need,
+__device__ __forceinline__ void solve_lanes(const CtxDev* __restrict__ C, const LdsView& L, double* wws, double* lgs, int glanes, bool need,
                                             double alpha, const double* v, const double* q, double min_omh, double* s0,
                                             double* c0, int& status, int& iters, int* nact_out, int* act_out,
                                             double* c_full, unsigned* ctr, int* hint_base, int* nhint_base, int cl,
                                             long long* prof = nullptr) {
     ctr[0] += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(need));
     bool fb = need;
+#ifdef LBMPC_PROFILE
+    const long long tp0 = clock64();
+#endif
     if (C->lane_solver) {
         double zf[NX];
         int st_f = 0, it_f = 0, na_f = 0, act_f[NX];
@@ -151,9 +157,60 @@ __device__ __forceinline__ void solve_lanes(const CtxDev* __restrict__ C, const 
         }
         fb = need && fb;
     }
+#ifdef LBMPC_PROFILE
+    const long long tp1 = clock64();
+    if (prof) prof[24] += tp1 - tp0;
+#endif
+    // instantiated for nx = 2, 3 (the 4x4 constants leave no LDS for its state; lbmpc_uqmpc_create clears gen_ok otherwise)
+    if constexpr (NX == 2 || NX == 3)
+    if (glanes > 0 && __builtin_amdgcn_ballot_w64(fb) != 0) {
+        constexpr int NZ = NX + 8;   // the instantiated shape: N * nu = 8 (every reference configuration); checked on the host
+        const int lane = lane_id();
+        for (int h0 = 0; h0 < LB_WAVE; h0 += glanes) {   // glanes lanes at a time share the wave's LDS region
+            const bool nd = fb && lane >= h0 && lane < h0 + glanes;
+            if (__builtin_amdgcn_ballot_w64(nd) == 0) continue;
+            ctr[14] += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(nd));
+            double zf[NZ];
+            int st_f = 0, it_f = 0, na_f = 0, act_f[LG_NQL];
+            bool fb2 = false;
+            lanegen_qp_solve<NX, NZ>(C, L, lgs, glanes, nd, alpha, v, q, min_omh, hint_base ? hint_base + (int64_t)cl * 16 : nullptr,
+                                     nhint_base ? nhint_base + cl : nullptr, zf, st_f, it_f, na_f, act_f, fb2, ctr + 9, prof ? prof + 16 : nullptr);
+            if (nd && !fb2) {
+#pragma unroll
+                for (int k = 0; k < NX; ++k) s0[k] = zf[k];
+#pragma unroll
+                for (int j = 0; j < LBMPC_MAX_NU; ++j) c0[j] = j < C->nu ? zf[NX + j] : 0.0;
+                status = st_f > status ? st_f : status;
+                iters += it_f;
+                if (nact_out) *nact_out = na_f;
+                if (act_out) {
+                    for (int a = 0; a < NZMAX; ++a) act_out[a] = -1;
+#pragma unroll
+                    for (int a = 0; a < LG_NQL; ++a)
+                        if (a < na_f) {  // ascending insertion
+                            int pos = a;
+                            while (pos > 0 && act_out[pos - 1] > act_f[a]) { act_out[pos] = act_out[pos - 1]; --pos; }
+                            act_out[pos] = act_f[a];
+                        }
+                }
+                if (c_full) {
+#pragma unroll
+                    for (int k = NX; k < NZ; ++k) c_full[k - NX] = zf[k];
+                }
+                fb = false;
+            }
+        }
+    }
+#ifdef LBMPC_PROFILE
+    const long long tp2 = clock64();
+    if (prof) prof[25] += tp2 - tp1;
+#endif
     if (__builtin_amdgcn_ballot_w64(fb) != 0)
         solve_flagged<NX>(C, L, wws, fb, alpha, v, q, s0, c0, status, iters, nact_out, act_out, c_full, ctr, hint_base,
                           nhint_base, cl, prof);
+#ifdef LBMPC_PROFILE
+    if (prof) prof[26] += clock64() - tp2;
+#endif
 }
 
 // ---- single-step kernel (lbmpc_uqmpc_step): lane per problem -------------------------------------
@@ -164,13 +221,14 @@ struct StepIO {
 };
 
 template <int NX>
-__global__ __launch_bounds__(256) void uqmpc_step_kernel(const CtxDev* __restrict__ C, int64_t batch, int uq, StepIO io) {
+__global__ __launch_bounds__(256) void uqmpc_step_kernel(const CtxDev* __restrict__ C, int64_t batch, int uq, int gen_lanes, StepIO io) {
     extern __shared__ double lds[];
     double* ws_base;
     const LdsView L = stage_constants(C, lds, &ws_base);
     const int wave = threadIdx.x / LB_WAVE, nwaves = blockDim.x / LB_WAVE, lane = lane_id();
     const int nz = C->nz, ncv = nz - NX;
     double* ws = ws_base + wave * ws_doubles(nz);
+    double* lgs = ws_base + nwaves * ws_doubles(nz) + wave * lanegen_doubles(gen_lanes);
     for (int64_t base = ((int64_t)blockIdx.x * nwaves + wave) * LB_WAVE; base < batch;
          base += (int64_t)gridDim.x * nwaves * LB_WAVE) {
         const int64_t b = base + lane;
@@ -194,8 +252,10 @@ __global__ __launch_bounds__(256) void uqmpc_step_kernel(const CtxDev* __restric
         double* cdst = (valid && io.c) ? io.c + b * ncv : nullptr;
         if (cdst) for (int k = 0; k < ncv; ++k) cdst[k] = 0.0;
         if (valid && io.active_set) for (int a = 0; a < NZMAX; ++a) io.active_set[b * NZMAX + a] = -1;
-        unsigned ctr[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        solve_lanes<NX>(C, L, ws, valid && need[0], alpha[0], v, q[0], momh[0], s0, c0, status, iters,
+        unsigned ctr[MC_NCTR];
+#pragma unroll
+        for (int i = 0; i < MC_NCTR; ++i) ctr[i] = 0;
+        solve_lanes<NX>(C, L, ws, lgs, gen_lanes, valid && need[0], alpha[0], v, q[0], momh[0], s0, c0, status, iters,
                         &nact, (valid && io.active_set) ? io.active_set + b * NZMAX : nullptr, cdst, ctr, nullptr, nullptr, 0);
         if (!valid) continue;
         if (io.s0) for (int k = 0; k < NX; ++k) io.s0[b * NX + k] = s0[k];
@@ -238,7 +298,7 @@ __global__ __launch_bounds__(256) void uqmpc_step_kernel(const CtxDev* __restric
 }
 
 #ifdef LBMPC_PROFILE
-__device__ unsigned long long lbmpc_prof[24];
+__device__ unsigned long long lbmpc_prof[48];
 __device__ unsigned long long lbmpc_prof_wave[3 * 4096];  // per wave: lifetime, solve ticks, rounds
 #define PROF_T(var) const long long var = clock64()
 #define PROF_ADD(slot, t0, t1) prof[slot] += (t1) - (t0)
@@ -250,17 +310,23 @@ __device__ unsigned long long lbmpc_prof_wave[3 * 4096];  // per wave: lifetime,
 #endif
 
 template <int NX, int T>
-__global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, SamplerDev smp, McArgs a) {
+__global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, McArgs a) {
     extern __shared__ double lds[];
     double* ws_base;
     const LdsView L = stage_constants(C, lds, &ws_base);
     const int wave = threadIdx.x / LB_WAVE, nwaves = blockDim.x / LB_WAVE, lane = lane_id();
     const int nz = C->nz, nu = C->nu, K = a.steps;
     double* ws = ws_base + wave * ws_doubles(nz);
-    const SamplerDev* S = &smp;
-    unsigned ctr[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // wave-uniform work counters (lbmpc_mc_counters)
+    double* lgs = ws_base + nwaves * ws_doubles(nz) + wave * lanegen_doubles(a.gen_lanes);
+    int* hist = reinterpret_cast<int*>(ws_base + nwaves * (ws_doubles(nz) + lanegen_doubles(a.gen_lanes)));   // MC_HIST_INTS
+    for (int i = threadIdx.x; i < MC_HIST_INTS; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    unsigned ctr[MC_NCTR];  // wave-uniform work counters (lbmpc_mc_counters)
+#pragma unroll
+    for (int i = 0; i < MC_NCTR; ++i) ctr[i] = 0;
 #ifdef LBMPC_PROFILE
-    long long prof[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long prof[48];
+    for (int i = 0; i < 48; ++i) prof[i] = 0;
     PROF_T(pk0);
 #endif
     // a.tpw trials per wave and per t (64 for large batches; fewer lanes per wave for small ones, so that the solver
@@ -291,21 +357,12 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
 #pragma unroll
             for (int i = 0; i < NX; ++i) { bTv[t][i] = 0.0; x[t][i] = 0.0; v[t][i] = 0.0; wst[t][i] = 0.0; }
             if (a.resume) continue;   // state arrives at step kpos
-            // initial set learning: InitialSetComputation.solve (:48-59), card_I0 samples
+            // initial set learning: InitialSetComputation.solve (:48-59).  The maxima over the card_I0 samples come from
+            // the pre-pass (sample_sets_kernel: lanes walk their own draws instead of waiting for the wave's slowest)
             double m[2 * NX];
 #pragma unroll
-            for (int r = 0; r < 2 * NX; ++r) m[r] = -LB_INF;
-            for (int i = 0; i < a.card_I0; ++i) {
-                double w[NX];
-                if (sample_w_I0<NX>(S, a.seed, tid[t], (uint32_t)i, 100, w)) status[t] = LBMPC_ST_SAMPLER_CAP;
-#pragma unroll
-                for (int r = 0; r < 2 * NX; ++r) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int k = 0; k < NX; ++k) acc = fma(C->box.WA[r * NX + k], w[k], acc);
-                    m[r] = acc > m[r] ? acc : m[r];
-                }
-            }
+            for (int r = 0; r < 2 * NX; ++r) m[r] = a.m0[cl[t] * (2 * NX) + r];
+            { const int s0i = a.i0_status[cl[t]]; status[t] = s0i > status[t] ? s0i : status[t]; }
             uint32_t mask;
             int st = homothety_box<NX>(&C->box, m, alpha[t], v[t], mask);
             status[t] = st > status[t] ? st : status[t];
@@ -443,9 +500,15 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
 #endif
                     if (__builtin_amdgcn_ballot_w64(nd) != 0) {
                         int nact_t = 0;
-                        solve_lanes<NX>(C, L, ws, nd, a_c[t], v_c[t], q_c[t], mo_c[t], s0[t], c0[t], status[t], iters[t],
+                        const int it0 = iters[t];
+                        solve_lanes<NX>(C, L, ws, lgs, a.gen_lanes, nd, a_c[t], v_c[t], q_c[t], mo_c[t], s0[t], c0[t], status[t], iters[t],
                                         &nact_t, nullptr, nullptr, ctr + 2, a.hint, a.nhint, cl_c[t], PROF_PTR);
-                        if (nd) hashint[t] = nact_t > 0;
+                        if (nd) {
+                            hashint[t] = nact_t > 0;
+                            const int di = iters[t] - it0;
+                            atomicAdd(hist + (di < 63 ? di : 63), 1);
+                            atomicAdd(hist + 64 + (nact_t < 63 ? nact_t : 63), 1);
+                        }
                     }
                 }
                 asm volatile("" : "+v"(pk));
@@ -542,12 +605,15 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, S
         }
     }
     if (lane == 0 && a.counters)
-        for (int i = 0; i < 11; ++i) atomicAdd(a.counters + i, (unsigned long long)ctr[i]);
+        for (int i = 0; i < MC_NCTR; ++i) if (ctr[i]) atomicAdd(a.counters + i, (unsigned long long)ctr[i]);
+    __syncthreads();
+    if (a.counters)
+        for (int i = threadIdx.x; i < MC_HIST_INTS; i += blockDim.x) if (hist[i]) atomicAdd(a.counters + 32 + i, (unsigned long long)hist[i]);
 #ifdef LBMPC_PROFILE
     PROF_T(pk1);
     prof[6] = pk1 - pk0;
     if (lane == 0) {
-        for (int i = 0; i < 24; ++i) if (i != 7) atomicAdd(&lbmpc_prof[i], (unsigned long long)prof[i]);
+        for (int i = 0; i < 48; ++i) if (i != 7) atomicAdd(&lbmpc_prof[i], (unsigned long long)prof[i]);
         atomicMax(&lbmpc_prof[7], (unsigned long long)prof[6]);  // slowest wave
         const int gw = blockIdx.x * nwaves + wave;
         if (gw < 4096) { lbmpc_prof_wave[3 * gw] = prof[6]; lbmpc_prof_wave[3 * gw + 1] = prof[2]; lbmpc_prof_wave[3 * gw + 2] = prof[5]; }
@@ -559,7 +625,7 @@ extern "C" int lbmpc_prof_read_waves(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(lbmpc_prof_wave), sizeof(unsigned long long) * 3 * 4096) == hipSuccess ? 0 : -1;
 }
 extern "C" int lbmpc_prof_read(unsigned long long* out, int reset) {
-    unsigned long long z[24] = {0};
+    unsigned long long z[48] = {0};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(lbmpc_prof), sizeof(z)) != hipSuccess) return -1;
     if (reset && hipMemcpyToSymbol(HIP_SYMBOL(lbmpc_prof), z, sizeof(z)) != hipSuccess) return -1;
     return 0;
@@ -656,6 +722,9 @@ extern "C" void lbmpc_destroy(lbmpc_ctx* c) {
     if (c->xi_status) (void)hipFree(c->xi_status);
     if (c->counters) (void)hipFree(c->counters);
     if (c->park) (void)hipFree(c->park);
+    if (c->m0) (void)hipFree(c->m0);
+    if (c->i0_status) (void)hipFree(c->i0_status);
+    if (c->smp_ph) (void)hipFree(c->smp_ph);
     if (c->smp_d) (void)hipFree(c->smp_d);
     if (c->hint) (void)hipFree(c->hint);
     if (c->st_d) (void)hipFree(c->st_d);
@@ -714,6 +783,21 @@ extern "C" int lbmpc_uqmpc_create(const lbmpc_params* p, lbmpc_ctx** out) {
     for (int i = 0; i < ncv; ++i) for (int j = 0; j < ncv; ++j) P2[(nx + i) * nz + nx + j] = 2.0 * CMX(p->Pc, ncv, i, j);
     if (!invert_gj(nz, P2.data(), Ginv.data())) { set_error("lbmpc_uqmpc_create: cost matrix is singular"); delete c; return LBMPC_ERR_ARG; }
     for (int i = 0; i < nz; ++i) for (int j = i + 1; j < nz; ++j) { double s = 0.5 * (Ginv[i * nz + j] + Ginv[j * nz + i]); Ginv[i * nz + j] = Ginv[j * nz + i] = s; }
+    // the one-QP-per-lane solver with H rows recomputes Ginv c from the row: Ginv must be blkdiag(dense nx x nx, diagonal)
+    // with exact zeros elsewhere (the inverse of a block-diagonal matrix by invert_gj keeps them exact), and nz = nx + 8
+    {
+        bool bd = nz == nx + 8 && (nx == 2 || nx == 3);
+        for (int i = 0; i < nz && bd; ++i)
+            for (int j = 0; j < nz; ++j) {
+                const bool inblock = (i < nx && j < nx) || i == j;
+                if (!inblock && Ginv[i * nz + j] != 0.0) { bd = false; break; }
+            }
+        const char* env_g = getenv("LBMPC_GEN_SOLVER");   // 0: skip the general lane solver (testing)
+        h.gen_ok = bd && !(env_g && atoi(env_g) == 0);
+        for (int i = 0; i < nx; ++i) for (int j = 0; j < nx; ++j) h.GiX[i * nx + j] = Ginv[i * nz + j];
+        for (int i = 0; i < LBMPC_MAX_NZ; ++i) h.Gd[i] = (i >= nx && i < nz) ? Ginv[i * nz + i] : 0.0;
+        h.nHs = nH + (h.gen_ok ? 1 : 0);   // the general lane solver reads the tail of an S row's coefficients from a row of zeros
+    }
     // S rows [S_b | S_A]; pad rows (b = 1e300, a = 0) can never be violated
     std::vector<double> Srow((size_t)h.nSp * h.RL, 0.0);
     for (int j = nS; j < h.nSp; ++j) Srow[(size_t)j * h.RL] = 1e300;
@@ -737,7 +821,7 @@ extern "C" int lbmpc_uqmpc_create(const lbmpc_params* p, lbmpc_ctx** out) {
         h.lane_solver = !(env_ls && atoi(env_ls) == 0);
     }
     // H rows: F_bar Psi^i, i = 0..Nu  (UQRobustMPC.m:153-155)
-    std::vector<double> Hm((size_t)nH * h.nzp, 0.0), M((size_t)nc * nz), M2((size_t)nc * nz);
+    std::vector<double> Hm((size_t)h.nHs * h.nzp, 0.0), M((size_t)nc * nz), M2((size_t)nc * nz);
     for (int r = 0; r < nc; ++r) for (int k = 0; k < nz; ++k) M[r * nz + k] = CMX(p->F_bar, nc, r, k);
     for (int i = 0; i <= p->Nu; ++i) {
         for (int r = 0; r < nc; ++r) for (int k = 0; k < nz; ++k) Hm[((size_t)i * nc + r) * h.nzp + k] = M[r * nz + k];
@@ -772,13 +856,29 @@ extern "C" int lbmpc_uqmpc_create(const lbmpc_params* p, lbmpc_ctx** out) {
 namespace lbmpc {
 static const size_t LDS_LIMIT = 160 * 1024;
 
-// waves per block so that constants + per-wave workspaces fit in 160 KiB of LDS
+// waves per block so that constants + per-wave workspaces (+ the block's histograms) fit in 160 KiB of LDS
 static int pick_waves(const lbmpc_ctx* c, int want) {
     const size_t wsb = (size_t)ws_doubles(c->h.nz) * 8;
     int w = want;
-    while (w > 1 && c->lds_const_bytes + (size_t)w * wsb > LDS_LIMIT) w >>= 1;
-    if (c->lds_const_bytes + (size_t)w * wsb > LDS_LIMIT) return 0;
+    while (w > 1 && c->lds_const_bytes + (size_t)w * wsb + MC_HIST_INTS * 4 > LDS_LIMIT) w >>= 1;
+    if (c->lds_const_bytes + (size_t)w * wsb + MC_HIST_INTS * 4 > LDS_LIMIT) return 0;
     return w;
+}
+// lanes of the per-wave LDS region of the general lane solver: the largest power of two <= min(lanes_per_wave, 32)
+// that fits beside the constants and the row-solver slots of `waves` waves; 0 when fewer than 4 fit or the solver
+// does not apply to this context.  LBMPC_GEN_LANES caps it (testing).
+static int pick_gen_lanes(const lbmpc_ctx* c, int waves, int lanes_per_wave) {
+    if (!c->h.gen_ok) return 0;
+    int cap = 32;
+    if (const char* e = getenv("LBMPC_GEN_LANES")) { const int v = atoi(e); if (v >= 0 && v <= 64) cap = v; }
+    const size_t base = c->lds_const_bytes + (size_t)waves * ws_doubles(c->h.nz) * 8 + MC_HIST_INTS * 4;
+    int gl = 64;
+    while (gl > cap || gl > lanes_per_wave) gl >>= 1;
+    while (gl >= 4 && base + (size_t)waves * lanegen_doubles(gl) * 8 > LDS_LIMIT) gl >>= 1;
+    return gl >= 4 ? gl : 0;
+}
+static size_t block_lds_bytes(const lbmpc_ctx* c, int waves, int gen_lanes) {
+    return c->lds_const_bytes + (size_t)waves * (ws_doubles(c->h.nz) + lanegen_doubles(gen_lanes)) * 8 + MC_HIST_INTS * 4;
 }
 
 template <class Kern>
@@ -791,21 +891,30 @@ static int allow_lds(Kern k, size_t bytes) {
 static int step_dev(lbmpc_ctx* c, int64_t batch, int uq, const StepIO& io, hipStream_t st) {
     const int waves = pick_waves(c, 4);
     if (!waves) { set_error("constants (%zu B) do not fit in LDS", c->lds_const_bytes); return LBMPC_ERR_DIM; }
-    const size_t lds = c->lds_const_bytes + (size_t)waves * ws_doubles(c->h.nz) * 8;
+    const int gen_lanes = pick_gen_lanes(c, waves, 64);
+    const size_t lds = block_lds_bytes(c, waves, gen_lanes);
     int64_t blocks = (batch + (int64_t)waves * 64 - 1) / ((int64_t)waves * 64);
     if (blocks > 1024) blocks = 1024;
     dim3 grid((unsigned)blocks), blk(waves * 64);
 #define LAUNCH_STEP(NXV)                                                                             \
     do {                                                                                             \
         if (int rc = allow_lds(uqmpc_step_kernel<NXV>, lds)) return rc;                              \
-        hipLaunchKernelGGL(uqmpc_step_kernel<NXV>, grid, blk, lds, st, c->d, batch, uq, io);         \
+        hipLaunchKernelGGL(uqmpc_step_kernel<NXV>, grid, blk, lds, st, c->d, batch, uq, gen_lanes, io); \
     } while (0)
+#ifdef LBMPC_DEV_FAST   // development build (Makefile `dev`): nx = 2, 3 only
+    switch (c->h.nx) {
+        case 2: LAUNCH_STEP(2); break;
+        case 3: LAUNCH_STEP(3); break;
+        default: set_error("development build: nx = 2, 3 only"); return LBMPC_ERR_UNSUPPORTED;
+    }
+#else
     switch (c->h.nx) {
         case 1: LAUNCH_STEP(1); break;
         case 2: LAUNCH_STEP(2); break;
         case 3: LAUNCH_STEP(3); break;
         default: LAUNCH_STEP(4); break;
     }
+#endif
 #undef LAUNCH_STEP
     LB_HIP(hipGetLastError());
     return 0;
@@ -871,7 +980,6 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
     const bool wide = env_t ? (atoi(env_t) == 2) : (cfg->trials >= (int64_t)256 * 8 * 128 * 2);
     const int waves = pick_waves(c, 8);
     if (!waves) { set_error("constants (%zu B) do not fit in LDS", c->lds_const_bytes); return LBMPC_ERR_DIM; }
-    const size_t lds = c->lds_const_bytes + (size_t)waves * ws_doubles(c->h.nz) * 8;
     // trials per wave: 64 once that still gives every SIMD a wave of its own (1024 SIMDs, with some slack), else fewer
     // lanes per wave so that small batches spread over the chip (measured: C3 10000 x 20 is fastest at 8, C1 65536 x 50
     // at 32; both solvers cost per wave-trip, whatever the number of live lanes)
@@ -879,6 +987,8 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
     while (tpw > 4 && (cfg->trials + tpw - 1) / tpw < 1088) tpw >>= 1;
     if (const char* env_w = getenv("LBMPC_MC_TPW")) { const int v = atoi(env_w); if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) tpw = v; }
     a.tpw = tpw;
+    a.gen_lanes = pick_gen_lanes(c, waves, tpw);
+    const size_t lds = block_lds_bytes(c, waves, a.gen_lanes);
     const int per_block = waves * tpw * (wide ? 2 : 1);
     // trial chunks: the pre-drawn disturbances of one chunk take steps * 2 nx * 8 B per trial
     const size_t per_trial = xi_bytes_for(c->h.nx, cfg->steps, 64) / 64;
@@ -906,8 +1016,8 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
             c->xi_status_n = (size_t)chunk;
         }
     }
-    if (!c->counters) LB_HIP(hipMalloc((void**)&c->counters, 12 * sizeof(unsigned long long)));
-    LB_HIP(hipMemsetAsync(c->counters, 0, 12 * sizeof(unsigned long long), st));
+    if (!c->counters) LB_HIP(hipMalloc((void**)&c->counters, MC_STATS_N * sizeof(unsigned long long)));
+    LB_HIP(hipMemsetAsync(c->counters, 0, MC_STATS_N * sizeof(unsigned long long), st));
     if ((size_t)chunk > c->hint_n) {
         if (c->hint) LB_HIP(hipFree(c->hint));
         c->hint = nullptr; c->hint_n = 0;
@@ -932,12 +1042,30 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
         LB_HIP(hipMalloc((void**)&c->st_i, (size_t)chunk * 5 * sizeof(int)));
         c->st_n = (size_t)chunk;
     }
+    if ((size_t)chunk > c->m0_n) {
+        if (c->m0) LB_HIP(hipFree(c->m0));
+        if (c->i0_status) LB_HIP(hipFree(c->i0_status));
+        c->m0 = nullptr; c->i0_status = nullptr; c->m0_n = 0;
+        LB_HIP(hipMalloc((void**)&c->m0, (size_t)chunk * 2 * c->h.nx * sizeof(double)));
+        LB_HIP(hipMalloc((void**)&c->i0_status, (size_t)chunk * sizeof(int)));
+        c->m0_n = (size_t)chunk;
+    }
+    if (!c->smp_ph) LB_HIP(hipMalloc((void**)&c->smp_ph, sizeof(SmpPhases)));
+    {
+        SmpPhases hp;
+        pack_sample_phases(sd, c->h.box.WA, 2 * c->h.nx, &hp);   // rows in the canonical order of the box
+        LB_HIP(hipMemcpyAsync(c->smp_ph, &hp, sizeof(SmpPhases), hipMemcpyHostToDevice, st));   // pageable source: staged before the call returns
+    }
+    a.m0 = c->m0; a.i0_status = c->i0_status;
     a.st_d = c->st_d; a.st_i = c->st_i;
     a.xi = c->xi; a.xi_status = c->xi_status; a.counters = c->counters;
     for (int64_t c0 = 0; c0 < cfg->trials; c0 += chunk) {
         const int64_t cn = cfg->trials - c0 < chunk ? cfg->trials - c0 : chunk;
         a.chunk0 = c0; a.chunk_n = cn;
         LB_HIP(hipMemsetAsync(a.nhint, 0, (size_t)cn * sizeof(int), st));
+        // information-set pre-pass: set (seed, trial) of card_I0 samples per trial, attempt cap 100 (InitialSetComputation.m:108)
+        if (int rc = launch_sample_sets(c->h.nx, c->h.nu, c->smp_ph, 2 * c->h.nx, cfg->card_I0, cn, cfg->seed, (uint64_t)(cfg->trial0 + c0), 100,
+                                        nullptr, c->m0, c->i0_status, st)) return rc;
         if (cfg->steps > 0) {
             LB_HIP(hipMemsetAsync(c->xi_status, 0, (size_t)cn * sizeof(int), st));
             // enough segments to put about 8 waves on every SIMD
@@ -965,8 +1093,16 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
 #define LAUNCH_MC(NXV, TV)                                                                      \
     do {                                                                                        \
         if (int rc = allow_lds(mc_kernel<NXV, TV>, lds)) return rc;                             \
-        hipLaunchKernelGGL((mc_kernel<NXV, TV>), grid, blk, lds, st, c->d, sd, a);              \
+        hipLaunchKernelGGL((mc_kernel<NXV, TV>), grid, blk, lds, st, c->d, a);                  \
     } while (0)
+#ifdef LBMPC_DEV_FAST
+#define LAUNCH_MC_ALL()                                                                         \
+    switch (c->h.nx * 2 + (wide ? 1 : 0)) {                                                     \
+        case 4: LAUNCH_MC(2, 1); break;                                                         \
+        case 6: LAUNCH_MC(3, 1); break;                                                         \
+        default: set_error("development build: nx = 2, 3, one trial per lane"); return LBMPC_ERR_UNSUPPORTED; \
+    }
+#else
 #define LAUNCH_MC_ALL()                                                                         \
     switch (c->h.nx * 2 + (wide ? 1 : 0)) {                                                     \
         case 2: LAUNCH_MC(1, 1); break;                                                         \
@@ -978,6 +1114,7 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
         case 8: LAUNCH_MC(4, 1); break;                                                         \
         default: LAUNCH_MC(4, 2); break;                                                        \
     }
+#endif
         a.kseg0 = 0; a.kseg1 = ksplit; a.resume = 0;
         LAUNCH_MC_ALL();
         if (ksplit < cfg->steps) {
@@ -1004,6 +1141,18 @@ extern "C" int lbmpc_mc_counters(lbmpc_ctx* c, uint64_t* out12) {
     if (guard.rc()) return guard.rc();
     LB_HIP(hipDeviceSynchronize());
     LB_HIP(hipMemcpy(out12, c->counters, 12 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int lbmpc_mc_stats(lbmpc_ctx* c, uint64_t* out, int n) {
+    if (int rc = check_any_device()) return rc;
+    if (!c || !out || n < 0) { set_error("lbmpc_mc_stats: bad argument"); return LBMPC_ERR_ARG; }
+    for (int i = 0; i < n; ++i) out[i] = 0;
+    if (!c->counters) return 0;
+    DeviceGuard guard(c->device);
+    if (guard.rc()) return guard.rc();
+    LB_HIP(hipDeviceSynchronize());
+    LB_HIP(hipMemcpy(out, c->counters, (size_t)(n < MC_STATS_N ? n : MC_STATS_N) * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -19,6 +19,7 @@ namespace lbmpc {
 
 struct CtxDev {
     int nx, nu, N, nc, Nu, nS, nW, nz, nH, RL, nzp, nSp;  // nSp: S row storage padded to a multiple of 128
+    int nHs;             // H rows stored (nH, + one row of zeros when gen_ok)
     double A[LBMPC_MAX_NX * LBMPC_MAX_NX];    // row-major
     double B[LBMPC_MAX_NX * LBMPC_MAX_NU];    // row-major nx x nu
     double K[LBMPC_MAX_NU * LBMPC_MAX_NX];    // row-major nu x nx
@@ -33,8 +34,10 @@ struct CtxDev {
     // row is violated at z = 0 (Cauchy-Schwarz: |a_j.q| <= sqrt(a_j' ME^-1 a_j) sqrt(q' ME q) <= b_j alpha (1-1e-6))
     double ME[LBMPC_MAX_NX * LBMPC_MAX_NX], bmin;
     double cmH[LBMPC_MAX_NZ];  // max_h |H[h,k]|: certificate that no H row is violated (qp_group.hpp, scan_rows)
+    double GiX[LBMPC_MAX_NX * LBMPC_MAX_NX], Gd[LBMPC_MAX_NZ];  // (2 Px)^-1 row-major nx x nx, diagonal of (2 Pc)^-1 (qp_lane_gen.hpp)
     int hasE;
     int lane_solver;     // 1: try the one-QP-per-lane solver of the S-row regime first (qp_lane.hpp)
+    int gen_ok;          // 1: the one-QP-per-lane solver with H rows (qp_lane_gen.hpp) applies: nz = nx + 8, Ginv block diagonal with a diagonal Pc block
     const double* Hm;    // nH x nzp: rows of F_bar Psi^i, i = 0..Nu
     const double* Ginv;  // nz x nz : (2 blkdiag(Px,Pc))^-1
 };
@@ -53,13 +56,17 @@ struct lbmpc_ctx {
     size_t xi_bytes = 0;
     int* xi_status = nullptr;
     size_t xi_status_n = 0;
-    unsigned long long* counters = nullptr;  // 12 work counters of the last mc_run
+    unsigned long long* counters = nullptr;  // MC_STATS_N work counters + histograms of the last mc_run
     int* hint = nullptr;                     // pivot candidates, 17 ints per chunk trial (16 rows + count)
     size_t hint_n = 0;
     double* st_d = nullptr;                  // trial state handed between step segments: (3 nx + 1) doubles ...
     int* st_i = nullptr;                     // ... and 5 ints per chunk trial
     size_t st_n = 0;
     lbmpc::SamplerDev* smp_d = nullptr;      // device copy of the sampler of the running lbmpc_mc_run (mc_sample_kernel stages it into LDS)
+    double* m0 = nullptr;                    // initial information sets of one trial chunk: maxima over the card(I0) samples, 2 nx (canonical rows) per trial
+    int* i0_status = nullptr;                // ... and their sampler-cap flags
+    size_t m0_n = 0;
+    lbmpc::SmpPhases* smp_ph = nullptr;      // draw descriptors of the information-set pre-pass (sample_sets_kernel)
     double* park = nullptr;                  // state parked during solves, PARK_SLOTS doubles per grid thread
     size_t park_bytes = 0;
 };
@@ -74,10 +81,13 @@ struct LdsView {
 };
 // LDS layout (doubles): [S rows | H rows | Ginv | pad to even | S32 (floats) | per-wave solver slots]
 __host__ __device__ inline int lds_const_doubles(const CtxDev& h) {
-    const int d64 = (h.nSp * h.RL + h.nH * h.nzp + h.nz * h.nz + 1) & ~1;
+    const int d64 = (h.nSp * h.RL + h.nHs * h.nzp + h.nz * h.nz + 1) & ~1;
     return d64 + (h.nSp * h.RL + 1) / 2;
 }
 __host__ __device__ inline int ws_doubles(int) { return 4 * 48; }  // GWS_PER_WAVE: four row slots per wave
+#define MC_NCTR 20        // work counters kept per wave in registers
+#define MC_STATS_N 160    // u64 slots of lbmpc_ctx::counters
+#define MC_HIST_INTS 128  // per-block LDS histograms (ints): iterations per QP solve [0, 64), final active-set size [64, 128)
 
 }  // namespace lbmpc
 
@@ -391,6 +401,7 @@ struct McArgs {
     double acc_bound, distance_error;
     int traj_trials, sampler_max_attempts;
     int tpw;  // trials per wave (and per t): 4 .. 64
+    int gen_lanes;  // lanes of the per-wave LDS region of the general lane solver (power of two <= tpw, 0: none)
     // step segment of this launch: [kseg0, kseg1); resume != 0: every trial continues from its saved state at step
     // st_i[kpos] (trials whose kpos is not inside the segment idle); state is saved at the end when kseg1 < steps
     int kseg0, kseg1, resume;
@@ -398,9 +409,11 @@ struct McArgs {
     int* st_i;     // [5][chunk trial]: status, infeasible, iters, hashint, kpos
     // this launch covers local trials [chunk0, chunk0 + chunk_n); xi holds their pre-drawn step disturbances
     int64_t chunk0, chunk_n;
+    const double* m0;       // [chunk trial][2 nx] maxima of W_A w over the initial information set (canonical rows), from the pre-pass
+    const int* i0_status;   // [chunk trial] LBMPC_ST_SAMPLER_CAP if one of its samplers hit the attempt cap
     const double* xi;       // pre-drawn step disturbances, layout xi_index()
     const int* xi_status;   // [chunk trial] LBMPC_ST_SAMPLER_CAP if a step sampler hit the attempt cap
-    unsigned long long* counters;  // 12 work counters of this launch
+    unsigned long long* counters;  // MC_STATS_N: work counters [0, 32), QP-iteration histogram [32, 96), active-set-size histogram [96, 160)
     int* hint;              // [chunk trial][16] final active set of the trial's previous step (pivot candidates)
     int* nhint;             // [chunk trial] its size
     double* park;           // [slot][thread of the grid]: closed-loop state parked during a solve (mc_kernel)

@@ -216,11 +216,18 @@ class Context:
 
     def mc_counters(self):
         """Work counters of the last Monte-Carlo launch (lbmpc_mc_counters)."""
-        buf = (C.c_uint64 * 12)()
-        _chk(self.lib.lbmpc_mc_counters(self.handle, buf), "lbmpc_mc_counters")
+        buf = (C.c_uint64 * 160)()
+        _chk(self.lib.lbmpc_mc_stats(self.handle, buf, 160), "lbmpc_mc_stats")
         names = ["filter_wave_steps", "wave_steps", "qp_solves", "solver_rounds", "solver_trips", "pivot_scans", "h_passes",
-                 "lane_trips", "lane_scans", "row_solver_qps", "lane_scan_qps"]
+                 "lane_trips", "lane_scans", "row_solver_qps", "lane_scan_qps", "gen_trips", "gen_scans", "gen_h_passes",
+                 "gen_scan_qps", "gen_rebuild_trips", "gen_qps"]
         return {n: int(buf[i]) for i, n in enumerate(names)}
+
+    def mc_histograms(self):
+        """(iterations per QP solve, final active-set size per QP solve) of the last Monte-Carlo launch, 64 bins each."""
+        buf = (C.c_uint64 * 160)()
+        _chk(self.lib.lbmpc_mc_stats(self.handle, buf, 160), "lbmpc_mc_stats")
+        return [int(buf[32 + i]) for i in range(64)], [int(buf[96 + i]) for i in range(64)]
 
     def mc_run(self, sampler, trials, steps, card_I0, seed, x0, acc_bound, distance_error, trial0=0, traj_trials=0,
                sampler_max_attempts=1000):

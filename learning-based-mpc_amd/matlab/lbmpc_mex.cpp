@@ -127,6 +127,22 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
                                                (uint64_t)mxGetScalar(prhs[5]), 100, mxGetDoubles(plhs[0]), mxGetDoubles(m), nullptr);
         if (rc < 0) fail("lbmpc:sample_sets", rc);
         if (nlhs > 1) plhs[1] = m;
+    } else if (cmd == "sample_polytope") {
+        // [x, status] = lbmpc_mex('sample_polytope', A, b, lo, hi, n, seed, stream, index0, purpose)
+        // n points uniform on {x : A x <= b} by rejection from the box [lo, hi]; point i is draw (seed, stream, index0 + i,
+        // purpose) of the library's Philox stream (ModelingCar.m:47-91 consume MATLAB's global rand instead)
+        need_args(nrhs, 10, "[x, status] = lbmpc_mex('sample_polytope', A, b, lo, hi, n, seed, stream, index0, purpose)");
+        const int nr = rows(prhs[1]), nx = cols(prhs[1]);
+        const int64_t n = (int64_t)mxGetScalar(prhs[5]);
+        if (rows(prhs[2]) * cols(prhs[2]) != nr || rows(prhs[3]) * cols(prhs[3]) != nx || rows(prhs[4]) * cols(prhs[4]) != nx || n < 0)
+            mexErrMsgIdAndTxt("lbmpc:sample_polytope", "A nr x nx, b nr, lo and hi nx, n >= 0");
+        plhs[0] = mxCreateDoubleMatrix(nx, n, mxREAL);
+        mxArray* st = mxCreateNumericMatrix(n, 1, mxINT32_CLASS, mxREAL);
+        int rc = lbmpc_sample_polytope(dbl(prhs[1]), dbl(prhs[2]), nr, nx, dbl(prhs[3]), dbl(prhs[4]), n, (uint64_t)mxGetScalar(prhs[6]),
+                                       (uint64_t)mxGetScalar(prhs[7]), (uint32_t)mxGetScalar(prhs[8]), (int)mxGetScalar(prhs[9]), 1000,
+                                       mxGetDoubles(plhs[0]), (int*)mxGetData(st));
+        if (rc < 0) fail("lbmpc:sample_polytope", rc);
+        if (nlhs > 1) plhs[1] = st;
     } else if (cmd == "create") {  // h = lbmpc_mex('create', p)  p: struct with the lbmpc_params fields (A,b unpacked)
         need_args(nrhs, 2, "h = lbmpc_mex('create', p [, ngpu])");
         const mxArray* s = prhs[1];

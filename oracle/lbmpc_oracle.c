@@ -660,9 +660,18 @@ static void row_coeffs(const orc_ctx* c, int j, double* cj) { /* c_j of c_j.z <=
  * the most violated one (ties: lowest row) is the pivot and no full pass over the rows is needed; otherwise the
  * most violated row of all (ties: lowest row).  Any rule that picks violated rows reaches the same, unique
  * minimiser; this one needs fewer full passes along a trajectory. */
+#ifdef ORC_STATS
+/* diagnostic build only (tools/qp_stats.py): per-solve histograms, single thread */
+long long orc_stats_hist[8][64]; /* [0] final nq, [1] max nq, [2] iterations, [3] full scans, [4] drops, [5] final H rows, [6] H rows scanned? */
+void orc_stats_reset(void) { memset(orc_stats_hist, 0, sizeof(orc_stats_hist)); }
+#define ST_BUMP(h, v) orc_stats_hist[h][(v) < 63 ? (v) : 63]++
+#endif
 static int qp_solve(const orc_ctx* c, const double* q, double alpha, const double* omh, double* z,
                     int* act, double* lam, int* nact_out, int* iters_out, const int* hint, int nhint) {
     int nz = c->nz, nx = c->nx, m = c->m, nq = 0, iters = 0, status = 0;
+#ifdef ORC_STATS
+    int st_maxnq = 0, st_scans = 0, st_drops = 0;
+#endif
     double CA[LBMPC_MAX_NZ][LBMPC_MAX_NZ]; /* active rows */
     double Wm[LBMPC_MAX_NZ][LBMPC_MAX_NZ]; /* Wm[a] = Ginv c_a */
     double u[LBMPC_MAX_NZ + 1];
@@ -683,6 +692,9 @@ static int qp_solve(const orc_ctx* c, const double* q, double alpha, const doubl
                 double s = row_slack(c, j, e, alpha, omh, z);
                 if (s < sp || (s == sp && p >= 0 && j < p)) { sp = s; p = j; }
             }
+#ifdef ORC_STATS
+        if (p < 0) st_scans++;
+#endif
         if (p < 0)
         for (int j = 0; j < m; ++j) {
             int isact = 0;
@@ -770,8 +782,14 @@ static int qp_solve(const orc_ctx* c, const double* q, double alpha, const doubl
                 memcpy(CA[nq], cp, sizeof(double) * nz);
                 memcpy(Wm[nq], g, sizeof(double) * nz);
                 nq++;
+#ifdef ORC_STATS
+                if (nq > st_maxnq) st_maxnq = nq;
+#endif
                 break;
             }
+#ifdef ORC_STATS
+            st_drops++;
+#endif
             /* drop constraint kdrop, stay in step 2 */
             for (int a = kdrop; a < nq - 1; ++a) {
                 act[a] = act[a + 1]; u[a] = u[a + 1];
@@ -783,6 +801,13 @@ static int qp_solve(const orc_ctx* c, const double* q, double alpha, const doubl
         }
     }
 done:
+#ifdef ORC_STATS
+    if (st_scans > 1 || nq > 0) { /* a QP the kernels would solve (not the trivial z = 0 confirmation) */
+        int nh = 0;
+        for (int a = 0; a < nq; ++a) nh += act[a] >= c->nS;
+        ST_BUMP(0, nq); ST_BUMP(1, st_maxnq); ST_BUMP(2, iters); ST_BUMP(3, st_scans); ST_BUMP(4, st_drops); ST_BUMP(5, nh);
+    }
+#endif
     for (int a = 0; a < nq; ++a) lam[a] = u[a];
     *nact_out = nq;
     *iters_out = iters;

@@ -255,3 +255,67 @@ def test_gateway_geometry_and_scmpc_commands(mex):
     np.testing.assert_array_equal(mex.field(R, "Control_EV_SCMPC").T.reshape(3, 10, 1), g["traj_u"])
     with pytest.raises(RuntimeError, match="lbmpc:field"):
         mex.call(1, "scmpc_mc_run", dict(N=8), sampler_struct(P), cfg)
+
+
+@pytest.mark.gpu
+def test_case_3_script_loop_through_the_gateway_equals_mc_run(mex):
+    """Case_3...:57-88 as matlab/ModelingCar.m + matlab/UQRobustMPC.m drive it -- 'sample_polytope' (purposes 3, 4, 5 at
+    step k of stream (seed, trial)) for the plant, 'step' for the controller, one call each per closed-loop step --
+    reproduces the trajectory of trial `trial` of 'mc_run' with the same seed, and the Python mirror api.ModelingCar
+    draws the same points."""
+    from lbmpc import api, core
+    core.init(0)
+    P = fixtures.params_dict()
+    mex.call(0, "init", 0)
+    seed, trial, K_N = 11, 3, 25
+    (hd,) = mex.call(1, "create", params_struct(P))
+    cfg = dict(trials=trial + 1, trial0=0, steps=K_N, card_I0=100, seed=seed, x0=np.array([-12.0, 5.0]), acc_bound=2.0,
+               distance_error=15.0, traj_trials=trial + 1)
+    (R,) = mex.call(1, "mc_run", hd, sampler_struct(P), cfg, raw=True)
+    X_ref = mex.field(R, "State_RM").T.reshape(trial + 1, K_N + 1, 2)[trial]
+    U_ref = mex.field(R, "Control_EV").T.reshape(trial + 1, K_N, 1)[trial]
+    a_ini = mex.field(R, "alpha_ini").ravel()[trial]
+    # InitialSetComputation.m wrapper: information set `trial` of stream `seed`
+    S, _ = mex.call(2, "sample_sets", sampler_struct(P), P["W_A"], 100, seed, trial)
+    al, v, _ = mex.call(3, "learn_set", P["W_A"], np.ravel(P["W_b"]), S)
+    assert float(al[0, 0]) == a_ini
+    A, B, x_des = P["A"], np.reshape(P["B"], (2, 1)), P["x_des"].reshape(-1, 1)
+    EV_A, EV_b, EV_V = P["Xi_EV_H"][:, :-1], P["Xi_EV_H"][:, -1], P["Xi_EV_V"]
+    LV_A, LV_b, LV_V = P["Xi_LV_H"][:, :-1], P["Xi_LV_H"][:, -1], P["Xi_LV_V"]
+    umin, umax = float(np.ravel(P["min_u_LV"])[0]), float(np.ravel(P["max_u_LV"])[0])
+    car = api.ModelingCar(dict(A=A, B=B, min_u_LV=umin, max_u_LV=umax, Xi_true_EV=api.Polyhedron(A=EV_A, b=EV_b, V=EV_V),
+                               Xi_true_LV=api.Polyhedron(A=LV_A, b=LV_b, V=LV_V)), seed=seed, stream=trial)
+
+    def draw(Ax, bx, V, k, purpose):       # ModelingCar.m, method draw
+        x, st = mex.call(2, "sample_polytope", Ax, bx, V.min(0), V.max(0), 1, seed, trial, k, purpose)
+        assert st.ravel()[0] == 0
+        return x
+
+    dims = [2, 1, 4, P["S_A"].shape[0], 4]
+    x_LV = np.array([[100.0], [10.0]])
+    x_EV = x_LV + x_des + np.array([[-12.0], [5.0]])
+    alpha_k, v_k = float(al[0, 0]), v
+    X, U = [x_EV - x_LV - x_des], []
+    for k in range(K_N):
+        xi_LV = draw(LV_A, LV_b, LV_V, k, 3)                                           # LVModeling
+        u_LV = draw(np.array([[1.0], [-1.0]]), np.array([umax, -umin]), np.array([[umin], [umax]]), k, 4)
+        x_LV_next = A @ x_LV + xi_LV + B * float(u_LV[0, 0])
+        xi_py, x_LV_py = car.LVModeling(x_LV)
+        np.testing.assert_array_equal(xi_py, xi_LV)
+        np.testing.assert_array_equal(x_LV_py, x_LV_next)
+        w_new = np.zeros((2, 1)) if k == 0 else X[k] - A @ X[k - 1] - B @ U[k - 1]
+        s_k, u_k, alpha_k, v_k = mex.call(4, "step", hd, 1, dims, X[k], alpha_k, v_k, w_new)   # UQRobustMPC.solve
+        alpha_k = float(alpha_k[0, 0])
+        xi_EV = draw(EV_A, EV_b, EV_V, k, 5)                                           # EVModeling
+        xi_py, x_EV_py = car.EVModeling(x_EV, u_k)
+        x_EV = A @ x_EV + B @ u_k + xi_EV
+        np.testing.assert_array_equal(xi_py, xi_EV)
+        np.testing.assert_array_equal(x_EV_py, x_EV)
+        x_LV = x_LV_next
+        U.append(u_k)
+        X.append(x_EV - x_LV - x_des)
+    np.testing.assert_allclose(np.hstack(X).T, X_ref, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(np.hstack(U).T, U_ref, rtol=0, atol=1e-9)
+    with pytest.raises(RuntimeError, match="lbmpc:sample_polytope"):
+        mex.call(1, "sample_polytope", EV_A, EV_b[:2], EV_V.min(0), EV_V.max(0), 1, 0, 0, 0, 5)
+    mex.call(0, "destroy", hd)
