@@ -128,6 +128,94 @@ __device__ __forceinline__ void lg_scan(const CtxDev* __restrict__ C, const LdsV
     }
 }
 
+
+// lowest row among the lanes' (value, row) pairs with the smallest value; val < -tol where a lane has a row.  The
+// common case -- one lane holds the minimum -- costs one fp64 reduction, a ballot and a readlane.
+__device__ __forceinline__ void lg_reduce(double val, int idx, double& best_out, int& bj_out) {
+    const double bmin = wave_min(val);
+    int j = 0x7fffffff;
+    if (bmin < -QP_TOL_VIOL) {
+        const uint64_t holders = __builtin_amdgcn_ballot_w64(val == bmin);
+        if ((holders & (holders - 1)) == 0) j = __builtin_amdgcn_readlane(idx, (int)__builtin_ctzll(holders));
+        else j = wave_min_i32(val == bmin ? idx : 0x7fffffff);
+    }
+    best_out = bmin; bj_out = j;
+}
+
+// lg_scan for tube sets of a few 64-row chunks (2x2: 128 padded rows): every lane keeps (slack, row) of its best S
+// and H row for each of the four QPs, so that one reduction per QP finishes the scan -- no second pass over the rows,
+// and the four reductions are independent instruction streams.  Same values, same tie rule.
+template <int NX, int NZ>
+__device__ __forceinline__ void lg_scan_small(const CtxDev* __restrict__ C, const LdsView& L, const double* ls, int lstr,
+                                              unsigned ncmagic, const int* src, double alpha, const double* e, const double* z,
+                                              bool wantH, double* best_out, int* bj_out, unsigned* hpasses) {
+    constexpr int RLc = NX + 1;
+    const int lane = lane_id();
+    const int nS = C->nS, nH = C->nH, nc = C->nc, nzp = C->nzp;
+    double best[4];
+    int bj[4], sln[4];
+    bool wh[4];
+    {
+        double ea[4], ee[4][NX];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            sln[g] = src[g] < 0 ? 0 : src[g];
+            ea[g] = readlane_f64(alpha, sln[g]);
+#pragma unroll
+            for (int k = 0; k < NX; ++k) ee[g][k] = readlane_f64(e[k], sln[g]);
+            best[g] = -QP_TOL_VIOL; bj[g] = 0x7fffffff;
+            wh[g] = src[g] >= 0 && __builtin_amdgcn_readlane((int)wantH, sln[g]) != 0;
+        }
+        const int nch = C->nSp >> 6;
+        for (int m = 0; m < nch; ++m) {   // pad rows (b = 1e300) are never violated
+            const double* row = L.Srow + (lane + 64 * m) * RLc;
+            double cf[RLc];
+#pragma unroll
+            for (int k = 0; k < RLc; ++k) cf[k] = row[k];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                double acc = ea[g] * cf[0];
+#pragma unroll
+                for (int k = 0; k < NX; ++k) acc = fma(cf[1 + k], ee[g][k], acc);
+                const bool lt = acc < best[g];
+                best[g] = lt ? acc : best[g];
+                bj[g] = lt ? lane + 64 * m : bj[g];
+            }
+        }
+    }
+    if (wh[0] || wh[1] || wh[2] || wh[3]) {
+        const int nchH = (nH + 63) >> 6;
+#pragma unroll
+        for (int g0 = 0; g0 < 4; g0 += 2) {
+            if (!wh[g0] && !wh[g0 + 1]) continue;
+            *hpasses += 1;
+            const int o0 = sln[g0] & (lstr - 1), o1 = sln[g0 + 1] & (lstr - 1);
+            double zu0[NZ], zu1[NZ];
+#pragma unroll
+            for (int k = 0; k < NZ; ++k) { zu0[k] = readlane_f64(z[k], sln[g0]); zu1[k] = readlane_f64(z[k], sln[g0 + 1]); }
+            for (int m = 0; m < nchH; ++m) {
+                const int h = lane + 64 * m;
+                const bool in = h < nH;
+                const int hc = in ? h : nH - 1;
+                const double* hp = L.Hm + hc * nzp;
+                const int r = hc - (int)__umulhi((unsigned)hc, ncmagic) * nc;
+                double row[NZ];
+#pragma unroll
+                for (int k = 0; k < NZ; ++k) row[k] = hp[k];
+                double a0 = ls[(LG_LP + r) * lstr + o0], a1 = ls[(LG_LP + r) * lstr + o1];
+#pragma unroll
+                for (int k = 0; k < NZ; ++k) { a0 = fma(-row[k], zu0[k], a0); a1 = fma(-row[k], zu1[k], a1); }
+                // strict <: an S row of this lane with the same slack keeps its (lower) index
+                const bool l0 = in && wh[g0] && a0 < best[g0], l1 = in && wh[g0 + 1] && a1 < best[g0 + 1];
+                best[g0] = l0 ? a0 : best[g0];             bj[g0] = l0 ? nS + h : bj[g0];
+                best[g0 + 1] = l1 ? a1 : best[g0 + 1];     bj[g0 + 1] = l1 ? nS + h : bj[g0 + 1];
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) lg_reduce(best[g], bj[g], best_out[g], bj_out[g]);
+}
+
 // Solve the QPs of the lanes flagged in `need` (one per lane; lanes >= lstr are never flagged).  On return, for every
 // flagged lane either fallback = true (nothing else is meaningful, the hint list is untouched) or z[0..NZ), status,
 // iters, nact, act[0..nact) (insertion order) are those of the oracle's qp_solve and the lane's hint list in HBM holds
@@ -243,7 +331,8 @@ __device__ __forceinline__ void lanegen_qp_solve(const CtxDev* __restrict__ C, c
                     }
                     double fb[4];
                     int fj[4];
-                    lg_scan<NX, NZ>(C, L, ls, lstr, ncmagic, src, alpha, e, z, pend_h, fb, fj, ctr + 2);
+                    if (C->nSp <= 256) lg_scan_small<NX, NZ>(C, L, ls, lstr, ncmagic, src, alpha, e, z, pend_h, fb, fj, ctr + 2);
+                    else lg_scan<NX, NZ>(C, L, ls, lstr, ncmagic, src, alpha, e, z, pend_h, fb, fj, ctr + 2);
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq)
                         if (lane == src[gq]) { best = fb[gq]; bj = fj[gq]; scanned = true; }

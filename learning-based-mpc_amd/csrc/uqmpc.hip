@@ -722,6 +722,8 @@ extern "C" void lbmpc_destroy(lbmpc_ctx* c) {
     if (c->xi_status) (void)hipFree(c->xi_status);
     if (c->counters) (void)hipFree(c->counters);
     if (c->park) (void)hipFree(c->park);
+    if (c->stg_d) (void)hipFree(c->stg_d);
+    if (c->stg_h) (void)hipHostFree(c->stg_h);
     if (c->m0) (void)hipFree(c->m0);
     if (c->i0_status) (void)hipFree(c->i0_status);
     if (c->smp_ph) (void)hipFree(c->smp_ph);
@@ -898,7 +900,10 @@ static int step_dev(lbmpc_ctx* c, int64_t batch, int uq, const StepIO& io, hipSt
     dim3 grid((unsigned)blocks), blk(waves * 64);
 #define LAUNCH_STEP(NXV)                                                                             \
     do {                                                                                             \
-        if (int rc = allow_lds(uqmpc_step_kernel<NXV>, lds)) return rc;                              \
+        if (lds > c->step_lds_set) {   /* once per context: the attribute call costs microseconds on the per-step path */ \
+            if (int rc = allow_lds(uqmpc_step_kernel<NXV>, lds)) return rc;                          \
+            c->step_lds_set = lds;                                                                   \
+        }                                                                                            \
         hipLaunchKernelGGL(uqmpc_step_kernel<NXV>, grid, blk, lds, st, c->d, batch, uq, gen_lanes, io); \
     } while (0)
 #ifdef LBMPC_DEV_FAST   // development build (Makefile `dev`): nx = 2, 3 only
@@ -920,6 +925,10 @@ static int step_dev(lbmpc_ctx* c, int64_t batch, int uq, const StepIO& io, hipSt
     return 0;
 }
 
+// Host-pointer form of one UQ-RMPC step.  This is the call a script makes once per closed-loop step (Case_3...:69-72,
+// batch = 1), so it allocates nothing after the first call of a given size: inputs and outputs go through one pinned
+// host block and one device block owned by the context (grow-only), one host-to-device copy, one launch, one
+// device-to-host copy of the outputs that were asked for.
 extern "C" int lbmpc_uqmpc_step(lbmpc_ctx* c, int64_t batch, int uq_update, const double* x, const double* alpha_prev,
                                 const double* v_prev, const double* w_new, double* s0, double* cc, double* u,
                                 double* alpha, double* v, double* hk, double* Sb_hat, double* Wb_hat, int* status,
@@ -932,26 +941,42 @@ extern "C" int lbmpc_uqmpc_step(lbmpc_ctx* c, int64_t batch, int uq_update, cons
     const CtxDev& h = c->h;
     const size_t B = (size_t)batch;
     const int ncv = h.nz - h.nx;
-    struct Out { void* host; size_t bytes; DevBuf buf; };
-    DevBuf dx, da, dv, dw;
-    LB_HIP(dx.alloc(B * h.nx * 8)); LB_HIP(da.alloc(B * 8)); LB_HIP(dv.alloc(B * h.nx * 8)); LB_HIP(dw.alloc(B * h.nx * 8));
-    LB_HIP(hipMemcpy(dx.p, x, B * h.nx * 8, hipMemcpyHostToDevice));
-    LB_HIP(hipMemcpy(da.p, alpha_prev, B * 8, hipMemcpyHostToDevice));
-    LB_HIP(hipMemcpy(dv.p, v_prev, B * h.nx * 8, hipMemcpyHostToDevice));
-    if (w_new) LB_HIP(hipMemcpy(dw.p, w_new, B * h.nx * 8, hipMemcpyHostToDevice));
-    Out outs[12] = {{s0, B * h.nx * 8, {}}, {cc, B * ncv * 8, {}}, {u, B * h.nu * 8, {}}, {alpha, B * 8, {}},
-                    {v, B * h.nx * 8, {}}, {hk, B * h.nc * 8, {}}, {Sb_hat, B * h.nS * 8, {}}, {Wb_hat, B * h.nW * 8, {}},
-                    {status, B * 4, {}}, {n_active, B * 4, {}}, {active_set, B * NZMAX * 4, {}}, {qp_iters, B * 4, {}}};
-    for (auto& o : outs) if (o.host) LB_HIP(o.buf.alloc(o.bytes));
+    // block layout (bytes): inputs x | alpha | v | w, then the outputs in the order below; every piece 8-byte aligned
+    const size_t in_bytes = B * (3 * (size_t)h.nx + 1) * 8;
+    struct Out { void* host; size_t bytes, off; };
+    Out outs[12] = {{s0, B * h.nx * 8, 0}, {cc, B * ncv * 8, 0}, {u, B * h.nu * 8, 0}, {alpha, B * 8, 0},
+                    {v, B * h.nx * 8, 0}, {hk, B * h.nc * 8, 0}, {Sb_hat, B * h.nS * 8, 0}, {Wb_hat, B * h.nW * 8, 0},
+                    {status, B * 4, 0}, {n_active, B * 4, 0}, {active_set, B * NZMAX * 4, 0}, {qp_iters, B * 4, 0}};
+    size_t total = in_bytes;
+    for (auto& o : outs) { o.off = total; if (o.host) total += (o.bytes + 7) & ~(size_t)7; }
+    if (total > c->stg_bytes) {
+        if (c->stg_d) LB_HIP(hipFree(c->stg_d));
+        if (c->stg_h) LB_HIP(hipHostFree(c->stg_h));
+        c->stg_d = nullptr; c->stg_h = nullptr; c->stg_bytes = 0;
+        const size_t cap = total < 65536 ? 65536 : total;
+        LB_HIP(hipMalloc(&c->stg_d, cap));
+        LB_HIP(hipHostMalloc(&c->stg_h, cap, hipHostMallocDefault));
+        c->stg_bytes = cap;
+    }
+    char* hb = static_cast<char*>(c->stg_h);
+    char* db = static_cast<char*>(c->stg_d);
+    double* hin = reinterpret_cast<double*>(hb);
+    std::memcpy(hin, x, B * h.nx * 8);
+    std::memcpy(hin + B * h.nx, alpha_prev, B * 8);
+    std::memcpy(hin + B * (h.nx + 1), v_prev, B * h.nx * 8);
+    if (w_new) std::memcpy(hin + B * (2 * h.nx + 1), w_new, B * h.nx * 8);
+    LB_HIP(hipMemcpyAsync(db, hb, in_bytes, hipMemcpyHostToDevice, nullptr));
+    double* din = reinterpret_cast<double*>(db);
     StepIO io;
-    io.x = dx.as<double>(); io.alpha_prev = da.as<double>(); io.v_prev = dv.as<double>(); io.w_new = w_new ? dw.as<double>() : nullptr;
-    io.s0 = outs[0].buf.as<double>(); io.c = outs[1].buf.as<double>(); io.u = outs[2].buf.as<double>();
-    io.alpha = outs[3].buf.as<double>(); io.v = outs[4].buf.as<double>(); io.hk = outs[5].buf.as<double>();
-    io.Sb_hat = outs[6].buf.as<double>(); io.Wb_hat = outs[7].buf.as<double>(); io.status = outs[8].buf.as<int>();
-    io.n_active = outs[9].buf.as<int>(); io.active_set = outs[10].buf.as<int>(); io.qp_iters = outs[11].buf.as<int>();
+    io.x = din; io.alpha_prev = din + B * h.nx; io.v_prev = din + B * (h.nx + 1); io.w_new = w_new ? din + B * (2 * h.nx + 1) : nullptr;
+    auto dptr_of = [&](int i) -> void* { return outs[i].host ? db + outs[i].off : nullptr; };
+    io.s0 = (double*)dptr_of(0); io.c = (double*)dptr_of(1); io.u = (double*)dptr_of(2); io.alpha = (double*)dptr_of(3);
+    io.v = (double*)dptr_of(4); io.hk = (double*)dptr_of(5); io.Sb_hat = (double*)dptr_of(6); io.Wb_hat = (double*)dptr_of(7);
+    io.status = (int*)dptr_of(8); io.n_active = (int*)dptr_of(9); io.active_set = (int*)dptr_of(10); io.qp_iters = (int*)dptr_of(11);
     if (int rc = step_dev(c, batch, uq_update, io, nullptr)) return rc;
-    LB_HIP(hipDeviceSynchronize());
-    for (auto& o : outs) if (o.host) LB_HIP(hipMemcpy(o.host, o.buf.p, o.bytes, hipMemcpyDeviceToHost));
+    if (total > in_bytes) LB_HIP(hipMemcpyAsync(hb + in_bytes, db + in_bytes, total - in_bytes, hipMemcpyDeviceToHost, nullptr));
+    LB_HIP(hipStreamSynchronize(nullptr));
+    for (auto& o : outs) if (o.host) std::memcpy(o.host, hb + o.off, o.bytes);
     return 0;
 }
 

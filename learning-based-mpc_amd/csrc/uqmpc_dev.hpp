@@ -67,6 +67,9 @@ struct lbmpc_ctx {
     int* i0_status = nullptr;                // ... and their sampler-cap flags
     size_t m0_n = 0;
     lbmpc::SmpPhases* smp_ph = nullptr;      // draw descriptors of the information-set pre-pass (sample_sets_kernel)
+    void *stg_d = nullptr, *stg_h = nullptr; // staging of lbmpc_uqmpc_step: one device block, one pinned host block (grow-only)
+    size_t stg_bytes = 0;
+    size_t step_lds_set = 0;                 // dynamic-LDS attribute already granted to this context's step kernel
     double* park = nullptr;                  // state parked during solves, PARK_SLOTS doubles per grid thread
     size_t park_bytes = 0;
 };
