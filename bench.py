@@ -13,12 +13,18 @@ metric (BASELINE.json): "closed-loop MPC steps/sec (batched MC trials, 4x4) + sa
                      directions, fp64-vector roofline.
   cpu_baseline     = the oracle (a CPU port, not MATLAB) on a bounded sample of the C4 workload: one thread and all
                      host cores (OpenMP over trials), rank 0 at N=1 only.
-One JSON line on rank 0.  Launch: python bench.py [--gpus N --steps K --warmup W]  (N>1 under torch.distributed.run).
+  latency          = config C1 at B = 1: one UQRobustMPC.solve per call through the host C ABI and through the MEX
+                     gateway (stand-in mex.h), median / p99 microseconds, beside the reference's stored 65.0 / 77.5 ms.
+One JSON line on rank 0.  Launch: python bench.py [--gpus N --steps K --warmup W].  With N > 1 and no launcher in the
+environment (WORLD_SIZE unset) it starts its own ranks, one process per GPU, through torch.distributed.run BEFORE
+anything touches a GPU, and exits with their code; under a launcher it is one of the ranks.
 """
 import argparse
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,7 +39,7 @@ import torch.distributed as dist
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X fp64 vector (non-MFMA) peak, BASELINE.md section 2.4
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
 
 
 def executed_flops(cnt, nx, nu, nc, nz, nS, nH, trial_steps):
@@ -48,15 +54,115 @@ def executed_flops(cnt, nx, nu, nc, nz, nS, nH, trial_steps):
                        + nx * (nx - 1)                  # two triangular solves
                        + nx + nx * nx                   # delta, primal direction
                        + 3 * nx) + 40.0                 # ratio test, updates; sqrt / divisions counted as one each
+    # general lane solver (qp_lane_gen.hpp), per trip and lane with about nq = 4 active rows: rhs and primal direction
+    # (2 nq nz each, + nq (nx^2 + nz - nx) for Ginv c), two triangular solves, ratio test; per drop-rebuild about as much again
+    nq = 4.0
+    gen_trip = 2.0 * (2 * nq * nz + nq * (nx * nx + nz - nx) + nq * nq + 2 * nz + 3 * nq) + 40.0
     return (trial_steps * per_step
-            + (cnt["pivot_scans"] + cnt["lane_scans"]) * 4.0 * 2.0 * (nx + 1) * nS + cnt["h_passes"] * 2.0 * 2.0 * nz * nH
-            + cnt["solver_trips"] * 4.0 * 6.0 * nz * nz + cnt["lane_trips"] * 64.0 * lane_trip)
+            + (cnt["pivot_scans"] + cnt["lane_scans"] + cnt.get("gen_scans", 0)) * 4.0 * 2.0 * (nx + 1) * nS
+            + (cnt["h_passes"] + cnt.get("gen_h_passes", 0)) * 2.0 * 2.0 * nz * nH
+            + cnt["solver_trips"] * 4.0 * 6.0 * nz * nz + cnt["lane_trips"] * 64.0 * lane_trip
+            + (cnt.get("gen_trips", 0) + cnt.get("gen_rebuild_trips", 0)) * 32.0 * gen_trip)
+
+
+def spawn_ranks(n, script, script_args, env=None):
+    """One process per GPU: `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... script args` as a child
+    of this process, which has not touched a GPU (a process that has must not be replaced or forked into ranks).
+    Returns the child's exit code.  tests/test_bench_launcher.py drives this with a CPU worker (gloo)."""
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n)}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script, *script_args]
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=e)
+
+
+def trim_hist(h):
+    """{bin: count} without the empty bins (bin 63 = 63 or more)"""
+    return {str(i): int(n) for i, n in enumerate(h) if n}
 
 
 def lib_sha256():
     from lbmpc import _abi
     with open(_abi.LIB_PATH, "rb") as f:
         return hashlib.sha256(f.read()).hexdigest()
+
+
+def latency_leg(core, params, n=2000):
+    """C1 at B = 1: one UQRobustMPC.solve (UQRobustMPC.m:68-91; timed by Case_3...:71-74) per call, on the
+    stored closed-loop states of Results_3_small (QP-active first steps included), (a) through the host C ABI with
+    pre-built arguments, (b) through mexFunction of the MEX gateway compiled against the stand-in mex.h."""
+    import ctypes as C
+    from lbmpc import _abi
+    P1 = params.load(os.path.join(ROOT, "tests", "golden", "params_2x2.npz"))
+    g3 = np.load(os.path.join(ROOT, "tests", "golden", "results_3_small.npz"))
+    X = np.ascontiguousarray(np.asarray(g3["State_RM"], dtype=np.float64).T[:50])        # 50 stored states x_k
+    ctx = core.Context(P1)
+    nx, nu, nc, nS, nW = ctx.nx, ctx.nu, ctx.nc, ctx.nS, ctx.nW
+    dp = _abi.dptr
+    a_in, v_in, w_in = np.array([0.3]), np.zeros(nx), np.zeros(nx)
+    o = dict(s0=np.zeros(nx), u=np.zeros(nu), alpha=np.zeros(1), v=np.zeros(nx), hk=np.zeros(nc), Sb=np.zeros(nS), Wb=np.zeros(nW))
+    st = np.zeros(1, np.int32)
+    lib, h = ctx.lib, ctx.handle
+    iptr = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+
+    xs = [dp(X[k]) for k in range(50)]      # argument pointers built once: the timed region is the call itself
+    pa, pv, pw, pst = dp(a_in), dp(v_in), dp(w_in), iptr(st)
+    po = {k: dp(a) for k, a in o.items()}
+
+    def one(k):
+        x = xs[k % 50]
+        t0 = time.perf_counter_ns()
+        rc = lib.lbmpc_uqmpc_step(h, 1, 1, x, pa, pv, pw, po["s0"], None, po["u"], po["alpha"], po["v"],
+                                  po["hk"], po["Sb"], po["Wb"], pst, None, None, None)
+        t1 = time.perf_counter_ns()
+        assert rc == 0
+        return (t1 - t0) * 1e-3
+    for k in range(200):
+        one(k)
+    t_abi = np.array([one(k) for k in range(n)])
+    out = {"workload": "C1 (2x2, parameters_2x2.mat), B = 1: one UQRobustMPC.solve per call on the 50 stored closed-loop states of "
+                       "Results_3_small.mat; 7 outputs incl. S_hat.b (nS doubles); host pointers in, host pointers out",
+           "c_abi_us": {"median": float(np.median(t_abi)), "p99": float(np.quantile(t_abi, 0.99)), "min": float(t_abi.min()), "calls": n},
+           "reference_stored_ms_per_step": {"Results_3_small": float(np.mean(g3["Time_UQMPC"]) * 1e3),
+                                            "Results_3_large": float(np.mean(np.load(os.path.join(ROOT, "tests", "golden", "results_3_large.npz"))["Time_UQMPC"]) * 1e3),
+                                            "source": "Time_UQMPC_*, Case_3...:71-74 (MATLAB + CasADi/IPOPT, hardware unknown)"}}
+    ctx.close()
+    try:   # MEX gateway through the stand-in mex.h (tests/mex_stub): what a MATLAB caller adds on top of the C ABI
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import test_mex_gateway as tm
+        mex = tm.Mex()
+        mex.call(0, "init", 0)
+        (hd,) = mex.call(1, "create", tm.params_struct(P1))
+        L = mex.L
+        dims = [nx, nu, nc, nS, nW]
+        prhs_sets = []
+        for k in range(50):
+            args_k = ("step", hd, 1, dims, X[k], 0.3, np.zeros(nx), np.zeros(nx))
+            prhs_sets.append((C.c_void_p * len(args_k))(*[mex.to_mx(a) for a in args_k]))
+        plhs = (C.c_void_p * 8)()
+        err = C.create_string_buffer(1024)
+
+        def one_mex(k):
+            pr = prhs_sets[k % 50]
+            t0 = time.perf_counter_ns()
+            rc = L.stub_call(7, plhs, 8, pr, err, 1024)
+            t1 = time.perf_counter_ns()
+            assert rc == 0, err.value
+            for i in range(7):
+                L.mxDestroyArray(plhs[i])
+            return (t1 - t0) * 1e-3
+        for k in range(200):
+            one_mex(k)
+        t_mex = np.array([one_mex(k) for k in range(n)])
+        out["mex_gateway_us"] = {"median": float(np.median(t_mex)), "p99": float(np.quantile(t_mex, 0.99)), "min": float(t_mex.min()), "calls": n,
+                                 "note": "mexFunction('step', ...) with 7 outputs allocated per call, stand-in mex.h (no MATLAB in the image)"}
+        mex.call(0, "destroy", hd)
+    except Exception as ex:   # the stub library is test infrastructure: its absence must not fail the benchmark
+        out["mex_gateway_us"] = {"error": repr(ex)}
+    return out
 
 
 def main():
@@ -78,9 +184,13 @@ def main():
                     help="rejection-sample xi from the axis-aligned vertex box (the reference's proposal) instead of the principal-axes box")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:   # no launcher: start the ranks ourselves (nothing has touched a GPU yet)
+        sys.exit(spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+
     from lbmpc import core, dev, dist as ldist, params
     rank, world, local = ldist.init_process_group()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     torch.cuda.set_device(local)
     core.init()                      # the device the launcher bound (never device 0 by default)
     device = torch.device("cuda", local)
@@ -144,6 +254,8 @@ def main():
     value = total_steps / dt
     iters_local = int(bufs.qp_iters.sum().item())
     cnt = ctx.mc_counters()
+    it_hist, na_hist = ctx.mc_histograms()
+    mc_launch = ctx.mc_plan(args.trials, args.horizon)
     exec64 = executed_flops(cnt, nx, nu_, nc_, nz, nS, nH, args.trials * args.horizon)
     exec32 = cnt["filter_wave_steps"] * 64.0 * 2.0 * (nx + 1) * nS
     achieved = exec64 / (kern_ms * 1e-3) / 1e12
@@ -153,6 +265,12 @@ def main():
     executed = {"fp64_flops_per_launch": exec64, "fp32_flops_per_launch": exec32, "counters": cnt,
                 "unpruned_equivalent_flops_per_launch": naive,
                 "unpruned_equivalent_tflops": naive / (kern_ms * 1e-3) / 1e12}
+    # SURVEY 8(d), subsystem 3: 2 (nS nx + nH nz) flops per constraint evaluation, (iterations + 1) evaluations per MPC
+    # step.  The kernels return the results of exactly that work (bit-equal to the oracle, which does evaluate every
+    # row) WITHOUT executing it -- ellipsoid certificate, fp32 filter, H-row certificate, candidate pivots -- so this is
+    # not a lower bound and the fraction exceeds 1: reported as the survey's figure, flagged pruned.
+    survey_flops = (args.trials * args.horizon + iters_local) * 2.0 * (nS * nx + nH * nz)
+    survey_tflops = survey_flops / (kern_ms * 1e-3) / 1e12
     c4_ref = {k: getattr(bufs, k)[:256].cpu().numpy() for k in ("infeasible", "qp_iters", "alpha_final", "x_final")}
 
     # ---------------------------------------------------------------- QP-active legs (rank-local, not aggregated)
@@ -170,6 +288,8 @@ def main():
                       trial0=0)
             ms = time_launches(lambda: dev.mc_run(cq, sq, bq, **kw), max(5, args.steps), warm=2)
             c = cq.mc_counters()
+            it_hist, na_hist = cq.mc_histograms()
+            plan = cq.mc_plan(trials, steps)
             parity = None
             if rank == 0:   # spot-check of the timed launch against the oracle on its first trials
                 o = oracle_core.Context(Pq).mc_run(sq, trials=check_trials, **kw)
@@ -185,6 +305,8 @@ def main():
             out = {"workload": f"{trials} trials x {steps} steps, card(I0)={card}", "ms_per_launch": ms,
                    "mpc_steps_per_s": trials * steps / (ms * 1e-3), "qp_solves_per_s": c["qp_solves"] / (ms * 1e-3),
                    "counters": c, "executed_fp64_tflops": fl / (ms * 1e-3) / 1e12,
+                   "qp_iterations_histogram": trim_hist(it_hist), "active_set_size_histogram": trim_hist(na_hist),
+                   "launch": plan,
                    "infeasible_trials": int(bq.infeasible.sum().item()), "max_status": int(bq.status.max().item()),
                    "parity": parity}
             cq.close()
@@ -260,6 +382,10 @@ def main():
                 "reference_stored_seconds": float(np.ravel(ref_stats[f"{nxo}x{nxo}_elapsedTime"])[0]),
                 "note": "offline_parameters_computation_nxn.m end to end (sets, tube, feasible regions, Ps) through the library; "
                         "reference: elapsedTime of its own stats_nxn.mat (MATLAB + MPT3 + IPOPT, hardware unknown)"}
+    # ---------------------------------------------------------------- per-step latency (C1, B = 1; rank 0 only)
+    latency = None
+    if not args.no_extra_legs and rank == 0:
+        latency = latency_leg(core, params)
     # ---------------------------------------------------------------- set learning (C2)
     P2 = params.load(os.path.join(ROOT, "tests", "golden", "params_2x2.npz"))
     smp2 = params.sampler(P2)
@@ -397,10 +523,20 @@ def main():
                        "trials_per_gpu": args.trials, "horizon": args.horizon, "nS": int(nS), "nH": int(nH), "nz": int(nz),
                        "parallelism": f"trial-sharded x{world}, no data-path collective",
                        "xi_proposal": "axis-aligned box" if args.axis_aligned_proposal else "principal-axes box"},
+            "qp_solves_per_s": cnt["qp_solves"] * world / (kern_ms * 1e-3),
             "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic_mc, "traffic_source": traffic_src,
                          "kernel": "mc_sample_kernel + mc_kernel (transient) + mc_steady_kernel",
                          "kernel_ms": kern_ms, "algorithmic_flops_per_launch": exec64, "executed": executed,
+                         "survey_8d_flops_per_launch": survey_flops, "survey_8d_tflops": survey_tflops,
+                         "survey_8d_frac": survey_tflops / FP64_VECTOR_PEAK_TFLOPS, "pruned": True,
+                         "certificate_only_wave_step_share": 1.0 - cnt["filter_wave_steps"] / max(1, cnt["wave_steps"]),
+                         "mpc_steps_with_a_qp_share": cnt["qp_solves"] / float(args.trials * args.horizon),
+                         "qp_iterations_histogram": trim_hist(it_hist), "active_set_size_histogram": trim_hist(na_hist),
+                         "occupancy": {"mc_kernel": mc_launch,
+                                       "note": "waves_per_simd = min(512 / registers_per_lane, waves_per_block x blocks per CU by LDS / 4); "
+                                               "lds_bytes_per_cu = dynamic LDS of the one block a CU holds; mc_steady_kernel and "
+                                               "mc_sample_kernel: profiles/r03_pmc_summary.json (VGPR_Count, LDS_Block_Size, SQ_WAVES)"},
                          "qp_solves_per_s_whole_launch": cnt["qp_solves"] / (kern_ms * 1e-3),
                          "note": "MFMA deliberately unused (north_star); bound is the fp64 vector rate. achieved prices the fp64 "
                                  "arithmetic the kernels of one step (pre-pass, transient, steady state; timed together) execute, counted by "
@@ -408,6 +544,7 @@ def main():
                                  "instructions are bookkeeping, not flops. 'unpruned_equivalent' is what a solver without the "
                                  "exact pruning (ellipsoid test, H-row certificate, candidate pivots) would execute"},
             "qp_active": qp_active,
+            "latency": latency,
             "set_learning": {"value": sl_value, "unit": "samples/s", "ms_per_step": sl_ms,
                              "config": {"workload": f"C2: 2x2 set learning, {B} information sets/GPU x {N} samples resident in HBM"},
                              "roofline": {"bound": "hbm", "achieved": sl_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

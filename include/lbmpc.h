@@ -389,6 +389,14 @@ int lbmpc_mc_counters(lbmpc_ctx* ctx, uint64_t* out12);
  * out[96 + k], k < 64: QP solves that ended with k active rows. */
 int lbmpc_mc_stats(lbmpc_ctx* ctx, uint64_t* out, int n);
 
+/* Launch shape and kernel resources lbmpc_mc_run would use for `trials` x `steps` on this context (occupancy
+ * and LDS bytes/CU of subsystem 3; no counterpart in the reference).  The first min(n, 11) of: out[0] trials per wave,
+ * [1] trials per lane, [2] waves per block, [3] dynamic LDS bytes per block (one block per CU), [4] lanes of the
+ * general lane solver's LDS region per wave (0: that tier is not available), [5] steps run by the transient kernel,
+ * [6] 1 if the steady-state kernel runs the rest, [7] registers per lane of the transient kernel, [8] its scratch bytes
+ * per lane, [9] resident waves per SIMD (the smaller of the register and LDS limits), [10] blocks of the transient launch. */
+int lbmpc_mc_plan(lbmpc_ctx* ctx, int64_t trials, int steps, int32_t* out, int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -68,15 +69,24 @@ static int load_rccl(Rccl** out) {
     return 0;
 }
 
-static int check_devices(const int* devices, int ngpu, std::vector<int>* out) {
+// LBMPC_MULTI_ALLOW_DUP=1 (testing on a box with fewer GPUs than shards): a device may be listed more than once, each
+// entry still gets its own context, host thread and shard.  The RCCL exchange needs distinct devices: with duplicates
+// lbmpc_halfspace_max_multi combines the per-shard maxima on the host instead.
+static bool allow_dup() { const char* e = getenv("LBMPC_MULTI_ALLOW_DUP"); return e && atoi(e) == 1; }
+static int check_devices(const int* devices, int ngpu, std::vector<int>* out, bool* has_dup = nullptr) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n < 1) { set_error("no HIP device visible"); return LBMPC_ERR_NODEVICE; }
-    if (ngpu < 1 || ngpu > n || ngpu > 64) { set_error("ngpu = %d outside [1, %d]", ngpu, n); return LBMPC_ERR_ARG; }
+    const bool dup_ok = allow_dup();
+    if (ngpu < 1 || (ngpu > n && !(dup_ok && devices)) || ngpu > 64) { set_error("ngpu = %d outside [1, %d]", ngpu, n); return LBMPC_ERR_ARG; }
     out->clear();
+    if (has_dup) *has_dup = false;
     for (int i = 0; i < ngpu; ++i) {
         const int d = devices ? devices[i] : i;
         if (d < 0 || d >= n) { set_error("device %d out of range [0,%d)", d, n); return LBMPC_ERR_ARG; }
-        if (std::find(out->begin(), out->end(), d) != out->end()) { set_error("device %d listed twice", d); return LBMPC_ERR_ARG; }
+        if (std::find(out->begin(), out->end(), d) != out->end()) {
+            if (!dup_ok) { set_error("device %d listed twice", d); return LBMPC_ERR_ARG; }
+            if (has_dup) *has_dup = true;
+        }
         out->push_back(d);
     }
     return 0;
@@ -179,26 +189,30 @@ extern "C" int lbmpc_halfspace_max_multi(const double* WA, int nW, int nx, const
     if (batch > 1 && batch_stride < N * nx) { set_error("lbmpc_halfspace_max_multi: batch_stride < N*nx"); return LBMPC_ERR_ARG; }
     if (batch == 0) return 0;
     std::vector<int> devs;
-    if (int rc = check_devices(devices, ngpu, &devs)) return rc;
+    bool has_dup = false;
+    if (int rc = check_devices(devices, ngpu, &devs, &has_dup)) return rc;
     const int G = std::min<int64_t>(ngpu, N) < 1 ? 1 : (int)std::min<int64_t>(ngpu, N);   // never an empty slice
     devs.resize(G);
     Rccl* R = nullptr;
-    if (int rc = load_rccl(&R)) return rc;
-    // communicators, kept per device list
+    if (!has_dup) if (int rc = load_rccl(&R)) return rc;
+    // communicators: one set per device list, created on first use and kept until the process ends
     static std::mutex mu;
-    static std::vector<int> comm_devs;
-    static std::vector<ncclComm_t> comms;
+    static std::map<std::vector<int>, std::vector<ncclComm_t>> comm_cache;
     std::lock_guard<std::mutex> lock(mu);
     int prev = -1;
     (void)hipGetDevice(&prev);
     struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{prev};
     for (int d : devs) if (int rc = lbmpc_init(d)) return rc;
-    if (comm_devs != devs) {
-        for (ncclComm_t c : comms) (void)R->CommDestroy(c);
-        comms.assign(G, nullptr); comm_devs.clear();
-        const int e = R->CommInitAll(comms.data(), G, devs.data());
-        if (e) { set_error("ncclCommInitAll -> %s", R->GetErrorString(e)); comms.clear(); return LBMPC_ERR_HIP; }
-        comm_devs = devs;
+    std::vector<ncclComm_t>* comms_p = nullptr;
+    if (!has_dup) {
+        auto it = comm_cache.find(devs);
+        if (it == comm_cache.end()) {
+            std::vector<ncclComm_t> fresh(G, nullptr);
+            const int e = R->CommInitAll(fresh.data(), G, devs.data());
+            if (e) { set_error("ncclCommInitAll -> %s", R->GetErrorString(e)); return LBMPC_ERR_HIP; }
+            it = comm_cache.emplace(devs, std::move(fresh)).first;
+        }
+        comms_p = &it->second;
     }
     std::vector<void*> dS(G, nullptr), dM(G, nullptr);
     std::vector<hipStream_t> st(G, nullptr);
@@ -223,11 +237,23 @@ extern "C" int lbmpc_halfspace_max_multi(const double* WA, int nW, int nx, const
                                 (size_t)count * nx * 8, (size_t)batch, hipMemcpyHostToDevice, st[g]));
         return lbmpc_halfspace_max_dev(WA, nW, nx, (const double*)dS[g], count, batch, count * nx, (double*)dM[g], st[g]);
     });
-    if (!rc) {   // the one exchange of this path
+    if (!rc && !has_dup) {   // the one exchange of this path
+        std::vector<ncclComm_t>& comms = *comms_p;
         int e = R->GroupStart();
         for (int g = 0; g < G && !e; ++g) e = R->AllReduce(dM[g], dM[g], (size_t)batch * nW, NCCL_FLOAT64, NCCL_MAX, comms[g], st[g]);
         const int e2 = R->GroupEnd();
         if (e || e2) { set_error("ncclAllReduce(max) -> %s", R->GetErrorString(e ? e : e2)); rc = LBMPC_ERR_HIP; }
+    }
+    if (!rc && has_dup) {   // LBMPC_MULTI_ALLOW_DUP: shards that share a device -- the maxima meet on the host
+        std::vector<double> acc((size_t)batch * nW, -INFINITY), part((size_t)batch * nW);
+        for (int g = 0; g < G && !rc; ++g) {
+            if (hipSetDevice(devs[g]) != hipSuccess || hipStreamSynchronize(st[g]) != hipSuccess ||
+                hipMemcpy(part.data(), dM[g], part.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) { set_error("copy of shard %d failed", g); rc = LBMPC_ERR_HIP; break; }
+            for (size_t i = 0; i < acc.size(); ++i) acc[i] = part[i] > acc[i] ? part[i] : acc[i];
+        }
+        if (!rc) std::memcpy(m_out, acc.data(), acc.size() * 8);
+        cleanup();
+        return rc;
     }
     if (!rc) {
         for (int g = 0; g < G && !rc; ++g) {

@@ -980,6 +980,89 @@ extern "C" int lbmpc_uqmpc_step(lbmpc_ctx* c, int64_t batch, int uq_update, cons
     return 0;
 }
 
+namespace lbmpc {
+// launch shape of the closed-loop kernels for a batch (shared by lbmpc_mc_run_dev and lbmpc_mc_plan)
+struct McPlan {
+    bool wide;        // two trials per lane
+    int waves, tpw, gen_lanes, per_block;
+    size_t lds;       // dynamic LDS per block of mc_kernel
+    int ksplit;       // steps run by the transient kernel
+    bool lean;        // the rest by mc_steady_kernel
+};
+static int mc_plan(const lbmpc_ctx* c, int64_t trials, int steps, McPlan* p) {
+    const char* env_t = getenv("LBMPC_MC_T");
+    // T = 2 trials per lane once 2-per-lane still fills every CU
+    p->wide = env_t ? (atoi(env_t) == 2) : (trials >= (int64_t)256 * 8 * 128 * 2);
+    p->waves = pick_waves(c, 8);
+    if (!p->waves) { set_error("constants (%zu B) do not fit in LDS", c->lds_const_bytes); return LBMPC_ERR_DIM; }
+    // trials per wave: 64 once that still gives every SIMD a wave of its own (1024 SIMDs, with some slack), else fewer
+    // lanes per wave so that small batches spread over the chip (every solver tier costs per wave-trip, whatever the
+    // number of live lanes)
+    int tpw = 64;
+    while (tpw > 4 && (trials + tpw - 1) / tpw < 1088) tpw >>= 1;
+    if (const char* env_w = getenv("LBMPC_MC_TPW")) { const int v = atoi(env_w); if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) tpw = v; }
+    p->tpw = tpw;
+    p->gen_lanes = pick_gen_lanes(c, p->waves, tpw);
+    p->lds = block_lds_bytes(c, p->waves, p->gen_lanes);
+    p->per_block = p->waves * tpw * (p->wide ? 2 : 1);
+    // Long horizons run in step segments: [0, ksplit) (transient, QPs) by mc_kernel, the rest by mc_steady_kernel from
+    // the saved state, then a resume launch of mc_kernel for the trials the steady kernel had to hand back (normally
+    // none).  LBMPC_MC_SPLIT moves the split point and LBMPC_MC_LEAN=0 leaves the steady kernel out (testing).
+    p->ksplit = steps >= 64 ? 32 : steps;
+    if (const char* env_s = getenv("LBMPC_MC_SPLIT")) { const int v = atoi(env_s); p->ksplit = (v > 0 && v < steps) ? v : steps; }
+    const char* env_l = getenv("LBMPC_MC_LEAN");
+    // the steady-state kernel is written for an exact box W and one input (every reference configuration)
+    p->lean = !(env_l && atoi(env_l) == 0) && c->h.box.exact && c->h.nu == 1;
+    return 0;
+}
+template <class Kern>
+static int kern_attrs(Kern k, int* vgprs, int* scratch, int* static_lds) {
+    hipFuncAttributes fa;
+    LB_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k)));
+    *vgprs = fa.numRegs; *scratch = (int)fa.localSizeBytes; *static_lds = (int)fa.sharedSizeBytes;
+    return 0;
+}
+}  // namespace lbmpc
+
+// out[0] trials per wave, [1] trials per lane, [2] waves per block, [3] dynamic LDS bytes per block (= per CU: one
+// block per CU), [4] lanes of the general lane solver's LDS region per wave (0: tier not available), [5] steps run by
+// the transient kernel, [6] 1 if mc_steady_kernel runs the rest; of the mc_kernel instantiation this batch uses:
+// [7] registers per lane (hipFuncAttributes::numRegs), [8] scratch bytes per lane, [9] resident waves per SIMD
+// = min(512 / registers, waves per block / 4 x blocks per CU by LDS); [10] blocks of the transient launch.
+extern "C" int lbmpc_mc_plan(lbmpc_ctx* c, int64_t trials, int steps, int32_t* out, int n) {
+    if (int rc = check_any_device()) return rc;
+    if (!c || !out || n < 0 || trials < 1 || steps < 0) { set_error("lbmpc_mc_plan: bad argument"); return LBMPC_ERR_ARG; }
+    DeviceGuard guard(c->device);
+    if (guard.rc()) return guard.rc();
+    McPlan p;
+    if (int rc = mc_plan(c, trials, steps, &p)) return rc;
+    int vg = 0, sc = 0, sl = 0, rc = 0;
+#ifdef LBMPC_DEV_FAST
+    switch (c->h.nx) { case 2: rc = kern_attrs(mc_kernel<2, 1>, &vg, &sc, &sl); break; default: rc = kern_attrs(mc_kernel<3, 1>, &vg, &sc, &sl); break; }
+#else
+    switch (c->h.nx * 2 + (p.wide ? 1 : 0)) {
+        case 2: rc = kern_attrs(mc_kernel<1, 1>, &vg, &sc, &sl); break;
+        case 3: rc = kern_attrs(mc_kernel<1, 2>, &vg, &sc, &sl); break;
+        case 4: rc = kern_attrs(mc_kernel<2, 1>, &vg, &sc, &sl); break;
+        case 5: rc = kern_attrs(mc_kernel<2, 2>, &vg, &sc, &sl); break;
+        case 6: rc = kern_attrs(mc_kernel<3, 1>, &vg, &sc, &sl); break;
+        case 7: rc = kern_attrs(mc_kernel<3, 2>, &vg, &sc, &sl); break;
+        case 8: rc = kern_attrs(mc_kernel<4, 1>, &vg, &sc, &sl); break;
+        default: rc = kern_attrs(mc_kernel<4, 2>, &vg, &sc, &sl); break;
+    }
+#endif
+    if (rc) return rc;
+    const int by_regs = vg > 0 ? 512 / vg : 8;
+    const int blocks_per_cu = (int)(LDS_LIMIT / p.lds) < 1 ? 1 : (int)(LDS_LIMIT / p.lds);
+    int by_lds = p.waves * blocks_per_cu / 4;
+    if (by_lds < 1) by_lds = 1;
+    int64_t blocks = (trials + p.per_block - 1) / p.per_block;
+    const int vals[11] = {p.tpw, p.wide ? 2 : 1, p.waves, (int)p.lds, p.gen_lanes, p.ksplit, p.lean ? 1 : 0, vg, sc,
+                          by_regs < by_lds ? by_regs : by_lds, (int)(blocks > 0x7fffffff ? 0x7fffffff : blocks)};
+    for (int i = 0; i < n && i < 11; ++i) out[i] = vals[i];
+    return 0;
+}
+
 extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lbmpc_mc_cfg* cfg, lbmpc_mc_out* out,
                                 void* stream) {
     if (int rc = check_any_device()) return rc;
@@ -1000,21 +1083,13 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
     a.traj_trials = cfg->traj_trials; a.sampler_max_attempts = cfg->sampler_max_attempts;
     a.out = *out;
     hipStream_t st = (hipStream_t)stream;
-    const char* env_t = getenv("LBMPC_MC_T");
-    // T = 2 trials per lane once 2-per-lane still fills every CU
-    const bool wide = env_t ? (atoi(env_t) == 2) : (cfg->trials >= (int64_t)256 * 8 * 128 * 2);
-    const int waves = pick_waves(c, 8);
-    if (!waves) { set_error("constants (%zu B) do not fit in LDS", c->lds_const_bytes); return LBMPC_ERR_DIM; }
-    // trials per wave: 64 once that still gives every SIMD a wave of its own (1024 SIMDs, with some slack), else fewer
-    // lanes per wave so that small batches spread over the chip (measured: C3 10000 x 20 is fastest at 8, C1 65536 x 50
-    // at 32; both solvers cost per wave-trip, whatever the number of live lanes)
-    int tpw = 64;
-    while (tpw > 4 && (cfg->trials + tpw - 1) / tpw < 1088) tpw >>= 1;
-    if (const char* env_w = getenv("LBMPC_MC_TPW")) { const int v = atoi(env_w); if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) tpw = v; }
+    McPlan plan;
+    if (int rc = mc_plan(c, cfg->trials, cfg->steps, &plan)) return rc;
+    const bool wide = plan.wide;
+    const int waves = plan.waves, tpw = plan.tpw, per_block = plan.per_block;
     a.tpw = tpw;
-    a.gen_lanes = pick_gen_lanes(c, waves, tpw);
-    const size_t lds = block_lds_bytes(c, waves, a.gen_lanes);
-    const int per_block = waves * tpw * (wide ? 2 : 1);
+    a.gen_lanes = plan.gen_lanes;
+    const size_t lds = plan.lds;
     // trial chunks: the pre-drawn disturbances of one chunk take steps * 2 nx * 8 B per trial
     const size_t per_trial = xi_bytes_for(c->h.nx, cfg->steps, 64) / 64;
     const char* env_g = getenv("LBMPC_MC_XI_GIB");
@@ -1050,14 +1125,8 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
         c->hint_n = (size_t)chunk;
     }
     a.hint = c->hint; a.nhint = c->hint + (size_t)c->hint_n * 16;
-    // Long horizons run in step segments: [0, ksplit) (transient, QPs) by mc_kernel, the rest by mc_steady_kernel from
-    // the saved state, then a resume launch of mc_kernel for the trials the steady kernel had to hand back (normally
-    // none).  LBMPC_MC_SPLIT moves the split point and LBMPC_MC_LEAN=0 leaves the steady kernel out (testing).
-    int ksplit = cfg->steps >= 64 ? 32 : cfg->steps;
-    if (const char* env_s = getenv("LBMPC_MC_SPLIT")) { const int v = atoi(env_s); ksplit = (v > 0 && v < cfg->steps) ? v : cfg->steps; }
-    const char* env_l = getenv("LBMPC_MC_LEAN");
-    // the steady-state kernel is written for an exact box W and one input (every reference configuration)
-    const bool lean = !(env_l && atoi(env_l) == 0) && c->h.box.exact && c->h.nu == 1;
+    const int ksplit = plan.ksplit;
+    const bool lean = plan.lean;
     const size_t lds_steady = steady_lds_bytes(c->h.nSp, c->h.RL, c->h.nx);
     if (ksplit < cfg->steps && (size_t)chunk > c->st_n) {
         if (c->st_d) LB_HIP(hipFree(c->st_d));

@@ -178,6 +178,7 @@ def declare(lib, prefix):
         lib.lbmpc_halfspace_max_noalloc.argtypes, lib.lbmpc_halfspace_max_noalloc.restype = sig["halfspace_max"] + [vp], ci
         lib.lbmpc_mc_counters.argtypes, lib.lbmpc_mc_counters.restype = [vp, C.POINTER(C.c_uint64)], ci
         lib.lbmpc_mc_stats.argtypes, lib.lbmpc_mc_stats.restype = [vp, C.POINTER(C.c_uint64), ci], ci
+        lib.lbmpc_mc_plan.argtypes, lib.lbmpc_mc_plan.restype = [vp, C.c_int64, ci, C.POINTER(C.c_int32), ci], ci
         lib.lbmpc_version.restype = ci
         lib.lbmpc_init.argtypes, lib.lbmpc_init.restype = [ci], ci
         lib.lbmpc_last_error.restype = C.c_char_p

@@ -223,6 +223,14 @@ class Context:
                  "gen_scan_qps", "gen_rebuild_trips", "gen_qps"]
         return {n: int(buf[i]) for i, n in enumerate(names)}
 
+    def mc_plan(self, trials, steps):
+        """launch shape + kernel resources of a Monte-Carlo launch (lbmpc_mc_plan)"""
+        buf = (C.c_int32 * 11)()
+        _chk(self.lib.lbmpc_mc_plan(self.handle, int(trials), int(steps), buf, 11), "lbmpc_mc_plan")
+        names = ["trials_per_wave", "trials_per_lane", "waves_per_block", "lds_bytes_per_cu", "gen_solver_lanes",
+                 "transient_steps", "steady_kernel", "registers_per_lane", "scratch_bytes_per_lane", "waves_per_simd", "blocks"]
+        return {n: int(buf[i]) for i, n in enumerate(names)}
+
     def mc_histograms(self):
         """(iterations per QP solve, final active-set size per QP solve) of the last Monte-Carlo launch, 64 bins each."""
         buf = (C.c_uint64 * 160)()

@@ -118,3 +118,34 @@ def test_multi_gpu_entry_points_on_the_devices_present():
         core.MultiContext(P, [0, 0])
     with pytest.raises(core.LbmpcError):
         core.MultiContext(P, list(range(ndev + 1)))
+
+
+@pytest.mark.gpu
+def test_multi_gpu_threads_and_shards_with_one_device_listed_several_times():
+    """LBMPC_MULTI_ALLOW_DUP=1 (test switch): the same GPU may appear several times in a device list, so that the code
+    a multi-GPU node runs -- one context, one host thread and one block shard per entry, slices of the caller's output
+    arrays (ragged shard sizes, traj_trials straddling a shard boundary), sample slices of every information set --
+    really executes on the one-GPU test box.  Only the RCCL all-reduce itself is replaced (by a host-side max): RCCL
+    needs distinct devices.  Results are bitwise those of the single-device entry points."""
+    import os
+    P = fixtures.params_dict()
+    smp = _abi.make_sampler(**fixtures.sampler_args(P))
+    core.init(0)
+    kw = dict(trials=1001, steps=9, card_I0=10, seed=13, x0=[-12.0, 5.0], acc_bound=2.0, distance_error=15.0, traj_trials=400)
+    ref = core.Context(P).mc_run(smp, **kw)
+    rng = np.random.default_rng(4)
+    S = rng.uniform(-0.3, 0.3, size=(7, 2, 5003))
+    want = core.halfspace_max(P["W_A"], S)
+    os.environ["LBMPC_MULTI_ALLOW_DUP"] = "1"
+    try:
+        for dl in ([0, 0], [0, 0, 0]):
+            mc = core.MultiContext(P, dl)          # 1001 = 501 + 500 = 334 + 334 + 333: traj_trials = 400 ends inside shard 0 / 1
+            got = mc.mc_run(smp, **kw)
+            for k in ref:
+                np.testing.assert_array_equal(ref[k], got[k], err_msg=f"{k} devices={dl}")
+            mc.close()
+            np.testing.assert_array_equal(core.halfspace_max_multi(P["W_A"], S, dl), want)
+    finally:
+        os.environ.pop("LBMPC_MULTI_ALLOW_DUP", None)
+    with pytest.raises(core.LbmpcError):
+        core.MultiContext(P, [0, 0])               # without the switch a repeated device stays an error
