@@ -318,15 +318,8 @@ def main():
         # polytope-support LP kernel), x_RM_0 near the boundary of F_N_Hat
         from lbmpc import api
         P3 = params.load("3x3")
-        S3 = api.Polyhedron(A=P3["S_A"], b=P3["S_b"])
         t_fr = time.perf_counter()
-        fr = api.ComputeFeasibleRegion(dict(S=S3, S_true=S3, S_hat_opt=S3, F=P3["F"], G=P3["G"], K=P3["K"], F_bar=P3["F_bar"],
-                                            Psi=P3["Psi"], nc=int(P3["nc"]), nx=3, nu=int(P3["nu"]), N=int(P3["N"]), Ps=None))
-        _, m3, _ = core.sample_information_sets(params.sampler(P3, oriented=True), P3["W_A"], 10, 1, seed=5, set0=0, want_samples=False)
-        a3, v3, _, _ = core.homothety_lp(P3["W_A"], P3["W_b"], m3[0])
-        S_hat3 = a3 * S3 + (1 - a3) * (np.linalg.inv(np.eye(3) - P3["Phi"]) @ v3)
-        _, F_N_Hat = fr.ComFeasibleRegion_UQMPC(S_hat3, fr.ComFeasibleRegion_UQMPC_Hs_ini(S_hat3))
-        x03 = api.case_5_initial_state(F_N_Hat.V)
+        x03, F_N_Hat = api.case_5_start(P3, oriented=True, card_I0=10, seed=5)
         t_fr = time.perf_counter() - t_fr
         qp_active["C3_3x3_case5"] = qp_leg("C3", P3, x03, 10000, 20, 10, 5)
         qp_active["C3_3x3_case5"]["x_RM_0"] = [float(t) for t in x03]

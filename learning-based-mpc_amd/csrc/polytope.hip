@@ -8,12 +8,18 @@
 // the reference samples with 5000 YALMIP projections + convhull (:153-203, :380-435): with it,
 // h_{F_N}(d) = h_{F_Ns}(d) + h_{S_hat}(d) is exact and the feasible region is returned as an H-rep template.
 //
-// One LP per lane: primal active-set method from z = 0 (projection of c onto the null space of the working rows,
-// ratio test with ties to the lowest row, Bland's rule on the multipliers), the same procedure and arithmetic as the
-// oracle's lp_support_one.  Lanes of a wave walk the rows together (every lane reads row j at the same time: one
-// broadcast load per row), the per-lane state (z, p, multipliers, the k x k Cholesky factor) lives in private memory.
-// An offline-geometry path: thousands of directions, not the closed loop.
+// Primal active-set method from z = 0 (projection of c onto the null space of the working rows, ratio test with ties
+// to the lowest row, Bland's rule on the multipliers), the same procedure and arithmetic as the oracle's
+// lp_support_one.  Two mappings of one kernel body:
+//   WAVE = false, one LP per lane: the lanes of a wave walk the rows together (every lane reads row j at the same
+//     time: one broadcast load per row); pays once there are enough LPs to fill the chip with 64 per wave;
+//   WAVE = true, one LP per wave: the ratio test is spread over the lanes (lane l takes rows l, l+64, ...: coalesced
+//     row loads, one wave arg-min with ties to the lowest row = the serial scan's choice), the small algebra (z, p,
+//     multipliers, the k x k Cholesky factor) is computed redundantly by every lane.  A minHRep of 1 662 rows is
+//     1 662 waves instead of 26: the offline scripts' LP batches are thousands, not hundreds of thousands.
+// An offline-geometry path, not the closed loop.
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "common.hpp"
@@ -22,13 +28,16 @@ namespace lbmpc {
 
 #define LP_MAX_ITERS 400
 
-__global__ __launch_bounds__(64) void polytope_support_kernel(const double* __restrict__ A /* m x n row-major, unit rows */,
+template <bool WAVE>
+__global__ __launch_bounds__(256) void polytope_support_kernel(const double* __restrict__ A /* m x n row-major, unit rows */,
                                                               const double* __restrict__ bn /* m x nb, scaled */, int m, int n,
                                                               const double* __restrict__ Cd /* n x nd */, int64_t nd, int64_t nb,
                                                               double* __restrict__ h_out, double* __restrict__ z_out,
                                                               int* __restrict__ status_out,
                                                               const int* __restrict__ skip /* nullable: row LP t ignores */) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t thread = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t t = WAVE ? thread / LB_WAVE : thread;   // LP of this lane
+    const int lane = lane_id();
     const bool valid = t < nd * nb;
     const int64_t tt = valid ? t : nd * nb - 1;
     const int64_t s = tt / nd, i0 = tt % nd;
@@ -78,8 +87,8 @@ __global__ __launch_bounds__(64) void polytope_support_kernel(const double* __re
         if (__builtin_amdgcn_ballot_w64(scan) != 0) {
             double best = LB_INF;
             int jb = -1;
-            for (int j = 0; j < m; ++j) {
-                const double* row = A + (size_t)j * n;   // wave-uniform address
+            for (int j = WAVE ? lane : 0; j < m; j += WAVE ? LB_WAVE : 1) {
+                const double* row = A + (size_t)j * n;   // WAVE: one row per lane; else a wave-uniform address
                 double ap = 0.0, az = 0.0;
                 for (int i = 0; i < n; ++i) { const double aji = row[i]; ap = fma(aji, p[i], ap); az = fma(aji, z[i], az); }
                 bool inW = false;
@@ -91,6 +100,11 @@ __global__ __launch_bounds__(64) void polytope_support_kernel(const double* __re
                     if (r < best) { best = r; jb = j; }
                 }
             }
+            if (WAVE) {   // smallest ratio over the lanes, ties to the lowest row: what the serial scan keeps
+                int jj = jb < 0 ? 0x7fffffff : jb;
+                wave_argmin(best, jj);
+                jb = jj == 0x7fffffff ? -1 : jj;
+            }
             if (scan) {
                 if (jb < 0) { status = LBMPC_ST_LP_UNBOUNDED; done = true; }
                 else {
@@ -100,12 +114,23 @@ __global__ __launch_bounds__(64) void polytope_support_kernel(const double* __re
             }
         }
     }
-    if (!valid) return;
+    if (!valid || (WAVE && lane != 0)) return;
     double val = 0.0;
     for (int i = 0; i < n; ++i) val = fma(c[i], z[i], val);
     h_out[t] = val;
     if (z_out) for (int i = 0; i < n; ++i) z_out[(size_t)t * n + i] = z[i];
     if (status_out) status_out[t] = status;
+}
+
+// one LP per wave until one LP per lane would still put two waves on every SIMD (LBMPC_LP_MAP=lane|wave forces one: testing)
+static void launch_support(int64_t total, const double* A, const double* bn, int m, int n, const double* Cd, int64_t nd, int64_t nb,
+                           double* h, double* z, int* st, const int* skip) {
+    bool wave = total < (int64_t)LB_WAVE * 2048;
+    if (const char* e = getenv("LBMPC_LP_MAP")) wave = e[0] == 'w' ? true : (e[0] == 'l' ? false : wave);
+    if (wave)
+        hipLaunchKernelGGL(polytope_support_kernel<true>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, nullptr, A, bn, m, n, Cd, nd, nb, h, z, st, skip);
+    else
+        hipLaunchKernelGGL(polytope_support_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, A, bn, m, n, Cd, nd, nb, h, z, st, skip);
 }
 
 }  // namespace lbmpc
@@ -116,7 +141,7 @@ extern "C" int lbmpc_polytope_support(const double* A, int m, int n, const doubl
                                       int64_t nd, double* h_out, double* z_out, int* status_out) {
     if (int rc = check_device()) return rc;
     if (!A || !b || !C || !h_out || m < 1 || n < 1 || nb < 0 || nd < 0) { set_error("lbmpc_polytope_support: bad argument"); return LBMPC_ERR_ARG; }
-    if (n > LBMPC_MAX_NZ || m > 65536) { set_error("lbmpc_polytope_support: n <= %d, m <= 65536", LBMPC_MAX_NZ); return LBMPC_ERR_DIM; }
+    if (n > LBMPC_MAX_NZ || m > 262144) { set_error("lbmpc_polytope_support: n <= %d, m <= 262144", LBMPC_MAX_NZ); return LBMPC_ERR_DIM; }
     if (nb == 0 || nd == 0) return 0;
     // unit rows (same operations as the oracle); a zero row never blocks
     std::vector<double> An((size_t)m * n), sc(m), bn((size_t)m * nb);
@@ -142,9 +167,8 @@ extern "C" int lbmpc_polytope_support(const double* A, int m, int n, const doubl
     LB_HIP(hipMemcpy(dA.p, An.data(), An.size() * 8, hipMemcpyHostToDevice));
     LB_HIP(hipMemcpy(db.p, bn.data(), bn.size() * 8, hipMemcpyHostToDevice));
     LB_HIP(hipMemcpy(dC.p, C, (size_t)nd * n * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(polytope_support_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, nullptr, dA.as<double>(),
-                       db.as<double>(), m, n, dC.as<double>(), nd, nb, dh.as<double>(), z_out ? dz.as<double>() : nullptr,
-                       status_out ? dst.as<int>() : nullptr, nullptr);
+    launch_support(total, dA.as<double>(), db.as<double>(), m, n, dC.as<double>(), nd, nb, dh.as<double>(), z_out ? dz.as<double>() : nullptr,
+                   status_out ? dst.as<int>() : nullptr, nullptr);
     LB_HIP(hipGetLastError());
     LB_HIP(hipMemcpy(h_out, dh.p, (size_t)total * 8, hipMemcpyDeviceToHost));
     if (z_out) LB_HIP(hipMemcpy(z_out, dz.p, (size_t)total * n * 8, hipMemcpyDeviceToHost));
@@ -159,7 +183,7 @@ extern "C" int lbmpc_polytope_support(const double* A, int m, int n, const doubl
 extern "C" int lbmpc_polytope_redundant(const double* A, int m, int n, const double* b, double* slack_out, int* status_out) {
     if (int rc = check_device()) return rc;
     if (!A || !b || !slack_out || m < 1 || n < 1) { set_error("lbmpc_polytope_redundant: bad argument"); return LBMPC_ERR_ARG; }
-    if (n > LBMPC_MAX_NZ || m > 65536) { set_error("lbmpc_polytope_redundant: n <= %d, m <= 65536", LBMPC_MAX_NZ); return LBMPC_ERR_DIM; }
+    if (n > LBMPC_MAX_NZ || m > 262144) { set_error("lbmpc_polytope_redundant: n <= %d, m <= 262144", LBMPC_MAX_NZ); return LBMPC_ERR_DIM; }
     std::vector<double> An((size_t)m * n), bn(m), h(m);
     std::vector<int> skip(m), st(m);
     for (int j = 0; j < m; ++j) {
@@ -180,9 +204,8 @@ extern "C" int lbmpc_polytope_redundant(const double* A, int m, int n, const dou
     LB_HIP(hipMemcpy(db.p, bn.data(), (size_t)m * 8, hipMemcpyHostToDevice));
     LB_HIP(hipMemcpy(dsk.p, skip.data(), (size_t)m * 4, hipMemcpyHostToDevice));
     // direction j = unit row j: the normalised row-major A doubles as the n x nd direction array
-    hipLaunchKernelGGL(polytope_support_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, nullptr, dA.as<double>(),
-                       db.as<double>(), m, n, dA.as<double>(), (int64_t)m, (int64_t)1, dh.as<double>(), nullptr, dst.as<int>(),
-                       dsk.as<int>());
+    launch_support(m, dA.as<double>(), db.as<double>(), m, n, dA.as<double>(), (int64_t)m, (int64_t)1, dh.as<double>(), nullptr, dst.as<int>(),
+                   dsk.as<int>());
     LB_HIP(hipGetLastError());
     LB_HIP(hipMemcpy(h.data(), dh.p, (size_t)m * 8, hipMemcpyDeviceToHost));
     LB_HIP(hipMemcpy(st.data(), dst.p, (size_t)m * 4, hipMemcpyDeviceToHost));

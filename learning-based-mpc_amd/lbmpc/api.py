@@ -461,6 +461,22 @@ def case_5_initial_state(V):
     return x
 
 
+def case_5_start(P, oriented=True, card_I0=10, seed=5):
+    """Case_5...:25-47 as written, for a flat parameter dict P: learn one information set of card_I0 samples, build
+    S_hat_ini, its tightening hs_ini and the feasible region F_N_Hat = F_Ns (+) S_hat_ini (ComputeFeasibleRegion on the
+    polytope-support LP kernel), and return (x_RM_0, F_N_Hat): the near-boundary start state of the feasibility study."""
+    from . import params
+    nx = int(P["nx"])
+    S = Polyhedron(A=P["S_A"], b=P["S_b"])
+    fr = ComputeFeasibleRegion(dict(S=S, S_true=S, S_hat_opt=S, F=P["F"], G=P["G"], K=P["K"], F_bar=P["F_bar"], Psi=P["Psi"],
+                                    nc=int(P["nc"]), nx=nx, nu=int(P["nu"]), N=int(P["N"]), Ps=None))
+    _, m, _ = core.sample_information_sets(params.sampler(P, oriented=oriented), P["W_A"], card_I0, 1, seed=seed, set0=0, want_samples=False)
+    a, v, _, _ = core.homothety_lp(P["W_A"], P["W_b"], m[0])
+    S_hat = a * S + (1 - a) * (np.linalg.inv(np.eye(nx) - np.asarray(P["Phi"], dtype=np.float64)) @ v)
+    _, F_N_Hat = fr.ComFeasibleRegion_UQMPC(S_hat, fr.ComFeasibleRegion_UQMPC_Hs_ini(S_hat))
+    return case_5_initial_state(F_N_Hat.V), F_N_Hat
+
+
 class ScenarioMPC:
     """fields: A, B, N_SC, Q, R, N, F, G, nu, nx, min_u_LV, max_u_LV, Xi_true_EV, Xi_true_LV (ScenarioMPC.m:30-48).
     solve(x_k) draws N_SC x N fresh scenarios on the device and returns u_k (:52-58); every call consumes the next

@@ -32,12 +32,19 @@ import time
 import numpy as np
 from scipy.linalg import solve_discrete_are
 
-from . import _abi, api, offline
+from . import _abi, api
+
+# 4x4 Xi rotations: QR of (I + pi/18 * G) with these fixed matrices stands in for MATLAB's randn under rng(42)
+# (offline_parameters_computation_nxn.m:90-96 -- not reproducible outside MATLAB; SURVEY.md hard part 5)
+G4_EV = np.array([[0.30, -0.14, 0.65, 1.52], [-0.23, -0.23, 1.58, 0.77], [-0.47, 0.54, -0.46, -0.47],
+                  [0.24, -1.91, -1.72, -0.56]])
+G4_LV = np.array([[-1.01, 0.31, -0.91, -1.41], [1.47, -0.23, 0.07, -1.42], [-0.54, 0.11, -1.15, 0.38],
+                  [-0.60, -0.29, -0.60, 1.85]])
 
 
 def definitions(nx, script="nxn"):
     """system, disturbance sets, prior W and constraint scales of offline_parameters_computation_nxn.m:17-99, :181-204,
-    :226-281 (3x3 / 4x4 as in lbmpc.offline, including its stand-in for the rng(42) rotations); script="2x2": see the
+    :226-281 (4x4: with the stand-in above for the rng(42) rotations); script="2x2": see the
     module docstring"""
     T, N, nu = 0.5, 8, 1
     A = np.eye(nx) * 0.5
@@ -72,8 +79,8 @@ def definitions(nx, script="nxn"):
             half_W, dist, acc = 1.5 * np.array([0.12, 0.08, 0.06]), 15.0, 4.0
         else:
             bits = np.array([[(i >> (3 - k)) & 1 for k in range(4)] for i in range(16)]) * 2.0 - 1.0
-            Q_EV, _ = np.linalg.qr(np.eye(4) + np.pi / 18 * offline.G4_EV)
-            Q_LV, _ = np.linalg.qr(np.eye(4) + np.pi / 18 * offline.G4_LV)
+            Q_EV, _ = np.linalg.qr(np.eye(4) + np.pi / 18 * G4_EV)
+            Q_LV, _ = np.linalg.qr(np.eye(4) + np.pi / 18 * G4_LV)
             V_EV = (bits * np.array([0.015, 0.01, 0.008, 0.012])) @ Q_EV.T
             V_LV = (bits * np.array([0.018, 0.009, 0.007, 0.011])) @ Q_LV.T
             half_W, dist, acc = np.array([0.12, 0.08, 0.06, 0.09]), 60.0, 60.0
@@ -120,10 +127,15 @@ def _hrep(P):
 
 
 def offline_parameters(nx, script="nxn", epsilon=None, mrpi_mode=_abi.MS_RAKOVIC, seed=0, n_template=None, n_region=None,
-                       log=None):
+                       log=None, n_template_S=None, rows_S=None, nu_floor=None):
     """Run the script for nx in {2, 3, 4}; returns (P, stats): P is the flat parameter dict of
     learning-based-mpc_amd/params/*.npz / tests/golden/params_2x2.npz (matio.save_parameters writes it as the
-    reference's `parameters` struct), stats the timing / size fields of the script's `stats` struct."""
+    reference's `parameters` struct), stats the timing / size fields of the script's `stats` struct.
+    n_template_S: template size of the tube set S alone (the other two sets keep n_template); rows_S: keep exactly
+    this many of the facets minHRep leaves (the axis and F + GK directions first; dropping facets of an irredundant
+    H-rep leaves an irredundant H-rep of a slightly larger outer approximation) -- the committed 3x3 / 4x4 sets take
+    the reference's facet counts this way (stats_*.mat: S_num_constraints = 795 / 1644, every row a facet as after its
+    minHRep, nxn.m:399,449,564); nu_floor: lower bound on Nu (the reference ran 3x3 with Nu = 47, Case_5...:5)."""
     say = log or (lambda *a: None)
     d = definitions(nx, script)
     epsilon = (1e-2 if script == "2x2" else 0.1) if epsilon is None else epsilon
@@ -161,10 +173,22 @@ def offline_parameters(nx, script="nxn", epsilon=None, mrpi_mode=_abi.MS_RAKOVIC
     Fc = Fc[np.linalg.norm(Fc, axis=1) > 0]
     D = np.vstack([api.template_directions(nx, n_template, seed=seed), Fc / np.linalg.norm(Fc, axis=1, keepdims=True)])
     sets = {}
+    n_must = 2 * nx + len(Fc)
     for name, Wset in (("S_hat_opt", W_hat_opt), ("S_true", W_true), ("S", W)):
         t = time.perf_counter()
-        Sraw, info = api.MRPISet(Phi, Wset, epsilon, template_directions=D, mode=mrpi_mode, seed=seed, return_info=True)
-        Smin = api.minHRep(Sraw)
+        Dn = D
+        if name == "S" and n_template_S is not None:
+            Dn = np.vstack([api.template_directions(nx, n_template_S, seed=seed), Fc / np.linalg.norm(Fc, axis=1, keepdims=True)])
+            Dn = np.vstack([Dn[:2 * nx], Dn[-len(Fc):], Dn[2 * nx:-len(Fc)]])      # axis and F + GK directions first
+        Sraw, info = api.MRPISet(Phi, Wset, epsilon, template_directions=Dn, mode=mrpi_mode, seed=seed, return_info=True)
+        Smin, keep = api.minHRep(Sraw, return_keep=True)
+        if name == "S" and rows_S is not None:
+            if len(keep) < rows_S:
+                raise RuntimeError(f"tube set: {len(keep)} facets from {len(Dn)} template rows, {rows_S} asked for: raise n_template_S")
+            if n_template_S is None:
+                raise ValueError("rows_S needs n_template_S (the directions to keep come first in that template)")
+            kept = keep[:rows_S]       # keep is ascending: the must-have directions (rows < n_must) stay
+            Smin = api.Polyhedron(A=Sraw.A[kept], b=Sraw.b[kept])
         key = {"S_hat_opt": "t_mrpi_shat", "S_true": "t_mrpi_strue", "S": "t_mrpi_s"}[name]
         stats[key] = time.perf_counter() - t
         stats[name + "_num_constraints"], stats[name + "_template_rows"] = len(Smin.b), len(Sraw.b)
@@ -178,6 +202,9 @@ def offline_parameters(nx, script="nxn", epsilon=None, mrpi_mode=_abi.MS_RAKOVIC
                nc=nc, nx=nx, nu=nu, N=N, num_half_space_S=len(sets["S"].b))
     reg = api.ComputeFeasibleRegion(fea, directions=None if n_region is None else api.template_directions(nx, n_region, seed))
     F_N_RMPC, hs_RMPC, Nu_RMPC = reg.ComFeasibleRegion_RMPC()
+    stats["Nu_exact"] = int(Nu_RMPC)
+    if nu_floor is not None and Nu_RMPC < nu_floor:
+        Nu_RMPC = int(nu_floor)      # rows F_bar Psi^i beyond nu_s are implied by the earlier ones: the same set Omega, more QP rows
     F_N_True, hs_True = reg.ComFeasibleRegion_True()
     F_N_Hat_Opt, hs_Hat_Opt = reg.ComFeasibleRegion_UQOPT()
     stats["t_feareg"] = time.perf_counter() - t
@@ -202,7 +229,9 @@ def offline_parameters(nx, script="nxn", epsilon=None, mrpi_mode=_abi.MS_RAKOVIC
              F_N_True_V=F_N_True.V, F_N_Hat_Opt_V=F_N_Hat_Opt.V, F_N_RMPC_H=np.hstack([F_N_RMPC.A, F_N_RMPC.b[:, None]]),
              F_N_Hat_Opt_H=np.hstack([F_N_Hat_Opt.A, F_N_Hat_Opt.b[:, None]]), x_des=x_des,
              distance_error=np.array([d["dist"]]), acc_bound=np.array([d["acc"]]), T=np.array([d["T"]]),
-             N_sam_opt=np.int64(len(samples_opt)), vol_W=np.array([np.prod(W.V.max(0) - W.V.min(0))]))
+             N_sam_opt=np.int64(len(samples_opt)), vol_W=np.array([np.prod(W.V.max(0) - W.V.min(0))]),
+             mrpi_s=np.int64(stats["S_s"]), mrpi_alpha=np.array([stats["S_alpha"]]), mrpi_eps=np.array([epsilon]),
+             Nu_exact=np.int64(stats["Nu_exact"]))
     return P, stats
 
 

@@ -14,7 +14,6 @@ from lbmpc import _abi, params
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-X03 = [-14.900000000001095, 14.700000000000186, 0.0]   # Case_5 near-boundary start of the committed 3x3 set
 
 
 @pytest.fixture(scope="module")
@@ -39,8 +38,9 @@ def _system(name):
     if name == "2x2":
         P = fixtures.params_dict()
         return P, _abi.make_sampler(**fixtures.sampler_args(P)), [-12.0, 5.0], 100, 1
+    from lbmpc import api
     P = params.load(name)
-    return P, params.sampler(P, oriented=True), X03, 10, 5
+    return P, params.sampler(P, oriented=True), [float(t) for t in api.case_5_start(P)[0]], 10, 5   # Case_5 near-boundary start
 
 
 @pytest.mark.parametrize("system,trials,steps", [("2x2", 1500, 30), ("3x3", 900, 20)])

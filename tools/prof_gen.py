@@ -9,9 +9,12 @@ LEG = os.environ.get("LEG", "C1")
 if LEG == "C1":
     P = params.load(os.path.join(ROOT, "tests", "golden", "params_2x2.npz")); x0 = [-12.0, 5.0]; trials, K, card, seed = 65536, 50, 100, 1
 else:
-    P = params.load("3x3"); x0 = [-14.900000000001095, 14.700000000000186, 0.0]; trials, K, card, seed = 10000, 20, 10, 5
+    P = params.load("3x3"); x0 = None; trials, K, card, seed = 10000, 20, 10, 5
 trials = int(os.environ.get("TRIALS", trials))
 core.init(0)
+if x0 is None:
+    from lbmpc import api
+    x0 = [float(t) for t in api.case_5_start(P)[0]]
 ctx = core.Context(P)
 smp = params.sampler(P, oriented=True)
 lib = _abi.load()

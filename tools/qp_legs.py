@@ -14,8 +14,7 @@ import torch
 
 from lbmpc import core, dev, params
 
-X03 = [-14.900000000001095, 14.700000000000186, 0.0]   # Case_5 near-boundary state of the committed 3x3 set (bench.py computes it)
-LEGS = {"C1": ("2x2", [-12.0, 5.0], 65536, 50, 100, 1), "C3": ("3x3", X03, 10000, 20, 10, 5),
+LEGS = {"C1": ("2x2", [-12.0, 5.0], 65536, 50, 100, 1), "C3": ("3x3", None, 10000, 20, 10, 5),   # C3: x0 = Case_5 near-boundary state (api.case_5_start)
         "C4t": ("4x4", [-12.0, 5.0, 0.0, 0.0], 131072, 32, 10, 4)}
 
 
@@ -28,6 +27,9 @@ def main():
     for name in names:
         system, x0, trials, steps, card, seed = LEGS[name]
         P = params.load(os.path.join(ROOT, "tests", "golden", "params_2x2.npz")) if system == "2x2" else params.load(system)
+        if x0 is None:
+            from lbmpc import api
+            x0 = [float(t) for t in api.case_5_start(P)[0]]
         ctx = core.Context(P)
         smp = params.sampler(P, oriented=True)
         b = dev.McBuffers(ctx, trials, device)
@@ -44,7 +46,7 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         cnt = ctx.mc_counters()
-        out = {"leg": name, "ms_per_launch": ms, "qp_solves_per_s": cnt["qp_solves"] / (ms * 1e-3), "counters": cnt,
+        out = {"leg": name, "x0": [float(t) for t in x0], "ms_per_launch": ms, "qp_solves_per_s": cnt["qp_solves"] / (ms * 1e-3), "counters": cnt,
                "infeasible": int(b.infeasible.sum().item()), "max_status": int(b.status.max().item()),
                "iters_sum": int(b.qp_iters.sum().item())}
         if check:

@@ -24,7 +24,8 @@ if which == "C1":
     x0, steps, card, seed = [-12.0, 5.0], 50, 100, 1
 elif which == "C3":
     P = params.load("3x3")
-    x0, steps, card, seed = [-14.900000000001095, 14.700000000000186, 0.0], 20, 10, 5
+    # Case_5 near-boundary start: api.case_5_start needs the GPU; take it from the environment (tools/qp_legs.py prints it)
+    x0, steps, card, seed = [float(t) for t in os.environ["X03"].split(",")], 20, 10, 5
 else:
     P = params.load("4x4")
     x0, steps, card, seed = [-12.0, 5.0, 0.0, 0.0], 32, 10, 4
