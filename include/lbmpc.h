@@ -384,7 +384,7 @@ int lbmpc_mc_counters(lbmpc_ctx* ctx, uint64_t* out12);
  * first min(n, 160) slots of: out[0..10] as lbmpc_mc_counters; the one-QP-per-lane solver with rows of F_bar Psi^i in
  * play (qp_lane_gen.hpp): out[11] loop trips (up to 64 QPs each), out[12] scan passes over the S rows (up to 4 QPs
  * each), out[13] passes over the H rows (2 QPs each), out[14] QPs served by the scan passes, out[15] trips that rebuilt
- * factor rows after a drop, out[16] QPs that entered this solver; out[17..31] reserved;
+ * factor rows after a drop, out[16] QPs that entered this solver, out[17] chunks of 64 H rows its scans evaluated (the others were certified); out[18..31] reserved;
  * out[32 + i], i < 64: QP solves that took i active-set iterations (i = 63: 63 or more);
  * out[96 + k], k < 64: QP solves that ended with k active rows. */
 int lbmpc_mc_stats(lbmpc_ctx* ctx, uint64_t* out, int n);

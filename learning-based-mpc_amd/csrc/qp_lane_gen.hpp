@@ -88,15 +88,16 @@ __device__ __forceinline__ double lg_slack(const CtxDev* __restrict__ C, const L
 template <int NX, int NZ>
 __device__ __forceinline__ void lg_scan(const CtxDev* __restrict__ C, const LdsView& L, const double* ls, int lstr,
                                         unsigned ncmagic, const int* src, double alpha, const double* e, const double* z,
-                                        bool wantH, double* best_out, int* bj_out, unsigned* hpasses) {
+                                        unsigned hmask /* chunks of 64 H rows this lane's QP needs */, double* best_out, int* bj_out, unsigned* hpasses) {
     scan_S_lanes<NX>(C, L, src, alpha, e, best_out, bj_out);
     const int lane = lane_id();
     const int nS = C->nS, nH = C->nH, nc = C->nc, nzp = C->nzp;
     const int nchH = (nH + 63) >> 6;
 #pragma unroll
     for (int g0 = 0; g0 < 4; g0 += 2) {
-        const bool w0 = src[g0] >= 0 && __builtin_amdgcn_readlane((int)wantH, src[g0] < 0 ? 0 : src[g0]);
-        const bool w1 = src[g0 + 1] >= 0 && __builtin_amdgcn_readlane((int)wantH, src[g0 + 1] < 0 ? 0 : src[g0 + 1]);
+        const unsigned m0 = src[g0] >= 0 ? (unsigned)__builtin_amdgcn_readlane((int)hmask, src[g0] < 0 ? 0 : src[g0]) : 0u;
+        const unsigned m1 = src[g0 + 1] >= 0 ? (unsigned)__builtin_amdgcn_readlane((int)hmask, src[g0 + 1] < 0 ? 0 : src[g0 + 1]) : 0u;
+        const bool w0 = m0 != 0, w1 = m1 != 0;
         if (!w0 && !w1) continue;
         *hpasses += 1;
         const int s0l = src[g0] < 0 ? 0 : src[g0], s1l = src[g0 + 1] < 0 ? 0 : src[g0 + 1];
@@ -107,6 +108,8 @@ __device__ __forceinline__ void lg_scan(const CtxDev* __restrict__ C, const LdsV
         double b0 = -QP_TOL_VIOL, b1 = -QP_TOL_VIOL;
         int j0 = 0x7fffffff, j1 = 0x7fffffff;
         for (int m = 0; m < nchH; ++m) {
+            if ((((m0 | m1) >> m) & 1u) == 0) continue;   // both QPs certify this chunk
+            hpasses[4] += 1;
             const int h = lane + 64 * m;
             const bool in = h < nH;
             const int hc = in ? h : nH - 1;
@@ -118,8 +121,8 @@ __device__ __forceinline__ void lg_scan(const CtxDev* __restrict__ C, const LdsV
             double a0 = ls[(LG_LP + r) * lstr + o0], a1 = ls[(LG_LP + r) * lstr + o1];
 #pragma unroll
             for (int k = 0; k < NZ; ++k) { a0 = fma(-row[k], zu0[k], a0); a1 = fma(-row[k], zu1[k], a1); }
-            if (in && w0 && a0 < b0) { b0 = a0; j0 = nS + h; }
-            if (in && w1 && a1 < b1) { b1 = a1; j1 = nS + h; }
+            if (in && ((m0 >> m) & 1u) && a0 < b0) { b0 = a0; j0 = nS + h; }
+            if (in && ((m1 >> m) & 1u) && a1 < b1) { b1 = a1; j1 = nS + h; }
         }
         wave_argmin(b0, j0);
         wave_argmin(b1, j1);
@@ -148,13 +151,13 @@ __device__ __forceinline__ void lg_reduce(double val, int idx, double& best_out,
 template <int NX, int NZ>
 __device__ __forceinline__ void lg_scan_small(const CtxDev* __restrict__ C, const LdsView& L, const double* ls, int lstr,
                                               unsigned ncmagic, const int* src, double alpha, const double* e, const double* z,
-                                              bool wantH, double* best_out, int* bj_out, unsigned* hpasses) {
+                                              unsigned hmask, double* best_out, int* bj_out, unsigned* hpasses) {
     constexpr int RLc = NX + 1;
     const int lane = lane_id();
     const int nS = C->nS, nH = C->nH, nc = C->nc, nzp = C->nzp;
     double best[4];
     int bj[4], sln[4];
-    bool wh[4];
+    unsigned wh[4];   // chunks of H rows QP g needs
     {
         double ea[4], ee[4][NX];
 #pragma unroll
@@ -164,7 +167,7 @@ __device__ __forceinline__ void lg_scan_small(const CtxDev* __restrict__ C, cons
 #pragma unroll
             for (int k = 0; k < NX; ++k) ee[g][k] = readlane_f64(e[k], sln[g]);
             best[g] = -QP_TOL_VIOL; bj[g] = 0x7fffffff;
-            wh[g] = src[g] >= 0 && __builtin_amdgcn_readlane((int)wantH, sln[g]) != 0;
+            wh[g] = src[g] >= 0 ? (unsigned)__builtin_amdgcn_readlane((int)hmask, sln[g]) : 0u;
         }
         const int nch = C->nSp >> 6;
         for (int m = 0; m < nch; ++m) {   // pad rows (b = 1e300) are never violated
@@ -183,17 +186,19 @@ __device__ __forceinline__ void lg_scan_small(const CtxDev* __restrict__ C, cons
             }
         }
     }
-    if (wh[0] || wh[1] || wh[2] || wh[3]) {
+    if ((wh[0] | wh[1] | wh[2] | wh[3]) != 0) {
         const int nchH = (nH + 63) >> 6;
 #pragma unroll
         for (int g0 = 0; g0 < 4; g0 += 2) {
-            if (!wh[g0] && !wh[g0 + 1]) continue;
+            if ((wh[g0] | wh[g0 + 1]) == 0) continue;
             *hpasses += 1;
             const int o0 = sln[g0] & (lstr - 1), o1 = sln[g0 + 1] & (lstr - 1);
             double zu0[NZ], zu1[NZ];
 #pragma unroll
             for (int k = 0; k < NZ; ++k) { zu0[k] = readlane_f64(z[k], sln[g0]); zu1[k] = readlane_f64(z[k], sln[g0 + 1]); }
             for (int m = 0; m < nchH; ++m) {
+                if ((((wh[g0] | wh[g0 + 1]) >> m) & 1u) == 0) continue;   // both QPs certify this chunk
+                hpasses[4] += 1;
                 const int h = lane + 64 * m;
                 const bool in = h < nH;
                 const int hc = in ? h : nH - 1;
@@ -206,7 +211,7 @@ __device__ __forceinline__ void lg_scan_small(const CtxDev* __restrict__ C, cons
 #pragma unroll
                 for (int k = 0; k < NZ; ++k) { a0 = fma(-row[k], zu0[k], a0); a1 = fma(-row[k], zu1[k], a1); }
                 // strict <: an S row of this lane with the same slack keeps its (lower) index
-                const bool l0 = in && wh[g0] && a0 < best[g0], l1 = in && wh[g0 + 1] && a1 < best[g0 + 1];
+                const bool l0 = in && ((wh[g0] >> m) & 1u) && a0 < best[g0], l1 = in && ((wh[g0 + 1] >> m) & 1u) && a1 < best[g0 + 1];
                 best[g0] = l0 ? a0 : best[g0];             bj[g0] = l0 ? nS + h : bj[g0];
                 best[g0 + 1] = l1 ? a1 : best[g0 + 1];     bj[g0 + 1] = l1 ? nS + h : bj[g0 + 1];
             }
@@ -220,7 +225,7 @@ __device__ __forceinline__ void lg_scan_small(const CtxDev* __restrict__ C, cons
 // flagged lane either fallback = true (nothing else is meaningful, the hint list is untouched) or z[0..NZ), status,
 // iters, nact, act[0..nact) (insertion order) are those of the oracle's qp_solve and the lane's hint list in HBM holds
 // this solve's active set.  ls: this wave's LG_SLOTS x lstr doubles of LDS.
-// ctr[0] += loop trips, ctr[1] += scan passes (S rows), ctr[2] += H-row passes, ctr[3] += QPs served by scans, ctr[4] += factor rebuilds (wave-uniform).
+// ctr[0] += loop trips, ctr[1] += scan passes (S rows), ctr[2] += H-row passes, ctr[3] += QPs served by scans, ctr[4] += factor rebuilds, ctr[6] += chunks of 64 H rows evaluated (wave-uniform).
 template <int NX, int NZ>
 __device__ __forceinline__ void lanegen_qp_solve(const CtxDev* __restrict__ C, const LdsView& L, double* ls, int lstr, bool need,
                                                  double alpha, const double* v, const double* q, double min_omh,
@@ -239,7 +244,8 @@ __device__ __forceinline__ void lanegen_qp_solve(const CtxDev* __restrict__ C, c
     double* lsl = ls + sl;                           // element `slot` of this lane: lsl[slot * lstr]
     const int nS = C->nS, nc = C->nc, nz = C->nz;
     const unsigned ncmagic = 0xFFFFFFFFu / (unsigned)nc + 1u;   // h % nc for h < 2^16
-    bool done = !need, have_p = false, pending = false, pend_h = false;
+    bool done = !need, have_p = false, pending = false;
+    unsigned pend_hm = 0;   // chunks of 64 H rows the pending full scan has to evaluate
     fallback = false;
     int nq = 0, p = 0, nh = 0;
     iters = 0; status = 0;
@@ -300,11 +306,17 @@ __device__ __forceinline__ void lanegen_qp_solve(const CtxDev* __restrict__ C, c
             }
             const bool need_full = s1 && bj == 0x7fffffff;
             if (__builtin_amdgcn_ballot_w64(need_full) != 0) {
-                // certificate that no H row is violated at z (scan_rows): the H pass is skipped for this lane
-                double t = 0.0;
+                // certificate that no H row of a chunk is violated at z (as scan_rows, per chunk of 64 rows): slack_h >=
+                // min_r (1-h_k)[r] - sum_k max_{h in chunk} |H[h,k]| |z_k| >= 1e-9; certified chunks are not evaluated
+                unsigned hm = 0;
+                const int nchH = (C->nH + 63) >> 6;
+                for (int m = 0; m < nchH; ++m) {
+                    double t = 0.0;
 #pragma unroll
-                for (int k = 0; k < NZ; ++k) t = fma(C->cmH[k], fabs(z[k]), t);
-                if (need_full) { pending = true; pend_h = !(t <= min_omh - 1e-9); }
+                    for (int k = 0; k < NZ; ++k) t = fma(C->cmHc[m][k], fabs(z[k]), t);
+                    hm |= (t <= min_omh - 1e-9) ? 0u : (1u << m);
+                }
+                if (need_full) { pending = true; pend_hm = hm; }
             }
             got = s1 && !pending;
         }
@@ -331,8 +343,8 @@ __device__ __forceinline__ void lanegen_qp_solve(const CtxDev* __restrict__ C, c
                     }
                     double fb[4];
                     int fj[4];
-                    if (C->nSp <= 256) lg_scan_small<NX, NZ>(C, L, ls, lstr, ncmagic, src, alpha, e, z, pend_h, fb, fj, ctr + 2);
-                    else lg_scan<NX, NZ>(C, L, ls, lstr, ncmagic, src, alpha, e, z, pend_h, fb, fj, ctr + 2);
+                    if (C->nSp <= 256) lg_scan_small<NX, NZ>(C, L, ls, lstr, ncmagic, src, alpha, e, z, pend_hm, fb, fj, ctr + 2);
+                    else lg_scan<NX, NZ>(C, L, ls, lstr, ncmagic, src, alpha, e, z, pend_hm, fb, fj, ctr + 2);
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq)
                         if (lane == src[gq]) { best = fb[gq]; bj = fj[gq]; scanned = true; }

@@ -836,6 +836,8 @@ extern "C" int lbmpc_uqmpc_create(const lbmpc_params* p, lbmpc_ctx** out) {
     }
     for (int k = 0; k < LBMPC_MAX_NZ; ++k) h.cmH[k] = 0.0;
     for (int r = 0; r < nH; ++r) for (int k = 0; k < nz; ++k) h.cmH[k] = std::max(h.cmH[k], std::fabs(Hm[(size_t)r * h.nzp + k]));
+    for (int m = 0; m < 32; ++m) for (int k = 0; k < LBMPC_MAX_NZ; ++k) h.cmHc[m][k] = 0.0;
+    for (int r = 0; r < nH; ++r) for (int k = 0; k < nz; ++k) h.cmHc[r >> 6][k] = std::max(h.cmHc[r >> 6][k], std::fabs(Hm[(size_t)r * h.nzp + k]));
     if (hipGetDevice(&c->device) != hipSuccess) { set_error("lbmpc_uqmpc_create: hipGetDevice failed"); delete c; return LBMPC_ERR_HIP; }
     auto fail = [&](hipError_t e, const char* what) { set_error("lbmpc_uqmpc_create: %s -> %s", what, hipGetErrorString(e)); lbmpc_destroy(c); return LBMPC_ERR_HIP; };
     hipError_t e;

@@ -34,6 +34,9 @@ struct CtxDev {
     // row is violated at z = 0 (Cauchy-Schwarz: |a_j.q| <= sqrt(a_j' ME^-1 a_j) sqrt(q' ME q) <= b_j alpha (1-1e-6))
     double ME[LBMPC_MAX_NX * LBMPC_MAX_NX], bmin;
     double cmH[LBMPC_MAX_NZ];  // max_h |H[h,k]|: certificate that no H row is violated (qp_group.hpp, scan_rows)
+    // the same bound per chunk of 64 H rows (the rows of late prediction stages shrink like rho(Phi)^i: most chunks certify
+    // even when the bound over all rows does not); used by the full scans of qp_lane_gen.hpp
+    double cmHc[32][LBMPC_MAX_NZ];
     double GiX[LBMPC_MAX_NX * LBMPC_MAX_NX], Gd[LBMPC_MAX_NZ];  // (2 Px)^-1 row-major nx x nx, diagonal of (2 Pc)^-1 (qp_lane_gen.hpp)
     int hasE;
     int lane_solver;     // 1: try the one-QP-per-lane solver of the S-row regime first (qp_lane.hpp)

@@ -220,7 +220,7 @@ class Context:
         _chk(self.lib.lbmpc_mc_stats(self.handle, buf, 160), "lbmpc_mc_stats")
         names = ["filter_wave_steps", "wave_steps", "qp_solves", "solver_rounds", "solver_trips", "pivot_scans", "h_passes",
                  "lane_trips", "lane_scans", "row_solver_qps", "lane_scan_qps", "gen_trips", "gen_scans", "gen_h_passes",
-                 "gen_scan_qps", "gen_rebuild_trips", "gen_qps"]
+                 "gen_scan_qps", "gen_rebuild_trips", "gen_qps", "gen_h_chunks"]
         return {n: int(buf[i]) for i, n in enumerate(names)}
 
     def mc_plan(self, trials, steps):
