@@ -6,6 +6,8 @@
 //
 // Replaces Functions_general/InitialSetComputation.m:48-99 (sampling loop, LP build, IPOPT solve)
 // and the sample rows of Functions_general/UQRobustMPC.m:124-139.
+#include <atomic>
+
 #include "common.hpp"
 
 namespace lbmpc {
@@ -248,19 +250,19 @@ extern "C" int lbmpc_halfspace_max_dev(const double* WA, int nW, int nx, const d
 // resolve_noalloc_scratch (called from lbmpc_init with that device current) and host code only ever uses that pointer.
 // Nothing in the array has to start at zero: every partial a launch reads was written by that launch's first kernel.
 static __device__ __align__(256) double scratch[LBMPC_NOALLOC_MAX_PARTIALS];
-static double* g_scratch_ptr[64];   // per device: device address of `scratch` on that GPU (nullptr: not resolved)
+static std::atomic<double*> g_scratch_ptr[64];   // per device: device address of `scratch` on that GPU (nullptr: not resolved); lbmpc_init may run on several threads
 
 namespace lbmpc {
 int resolve_noalloc_scratch(int device /* current on the calling thread */) {
     if (device < 0 || device >= 64) { set_error("resolve_noalloc_scratch: device %d out of range", device); return LBMPC_ERR_ARG; }
-    if (g_scratch_ptr[device]) return 0;
+    if (g_scratch_ptr[device].load(std::memory_order_acquire)) return 0;
     double* ptr = nullptr;
     const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
     if (e != hipSuccess || !ptr) {
         set_error("hipGetSymbolAddress(scratch) on device %d -> %s", device, hipGetErrorString(e));
         return LBMPC_ERR_HIP;
     }
-    g_scratch_ptr[device] = ptr;
+    g_scratch_ptr[device].store(ptr, std::memory_order_release);
     return 0;
 }
 }  // namespace lbmpc
@@ -272,7 +274,7 @@ extern "C" int lbmpc_halfspace_max_noalloc(const double* WA, int nW, int nx, con
     if (batch == 0) return 0;
     int device = -1;
     LB_HIP(hipGetDevice(&device));
-    double* ptr = (device >= 0 && device < 64) ? g_scratch_ptr[device] : nullptr;
+    double* ptr = (device >= 0 && device < 64) ? g_scratch_ptr[device].load(std::memory_order_acquire) : nullptr;
     if (!ptr) { set_error("lbmpc_halfspace_max_noalloc: scratch of device %d was not resolved by lbmpc_init", device); return LBMPC_ERR_NODEVICE; }
     int chunks; int64_t spc;
     plan_chunks(N, batch, hmax_spl(nx), &chunks, &spc);
@@ -472,13 +474,19 @@ int pack_sampler(const lbmpc_sampler* s, SamplerDev* o) {
         const int nx = s->nx;
         int nk = 0;
         for (int r = 0; r < nr; ++r) {
+            // mag bounds the magnitudes that enter the kernel's evaluation a.(U t): sum_k |a_k| sum_i |U_ki| max|t_i| (not
+            // |g_i| = |a.U_i|, which cancellation can make tiny for a skewed basis while the rounding stays O(|a||U||t|))
             double hmax = 0.0, mag = std::fabs(b[r]);
             for (int i = 0; i < nx; ++i) {   // g_i = a . (column i of U): the row in proposal coordinates
-                double g = 0.0;
-                for (int k = 0; k < nx; ++k) g += A[r + (size_t)nr * k] * (U ? U[k + (size_t)nx * i] : (k == i ? 1.0 : 0.0));
+                double g = 0.0, gabs = 0.0;
+                for (int k = 0; k < nx; ++k) {
+                    const double uki = U ? U[k + (size_t)nx * i] : (k == i ? 1.0 : 0.0);
+                    g += A[r + (size_t)nr * k] * uki;
+                    gabs += std::fabs(A[r + (size_t)nr * k]) * std::fabs(uki);
+                }
                 const double w = hi[i] - lo[i], inset = 0x1.0p-33 * w;
                 hmax += g > 0.0 ? g * (hi[i] - inset) : g * (lo[i] + inset);
-                mag += std::fabs(g) * (std::fabs(lo[i]) > std::fabs(hi[i]) ? std::fabs(lo[i]) : std::fabs(hi[i]));
+                mag += gabs * (std::fabs(lo[i]) > std::fabs(hi[i]) ? std::fabs(lo[i]) : std::fabs(hi[i]));
             }
             if (std::isfinite(hmax) && hmax + 1e-13 * mag <= b[r]) continue;   // never violated
             for (int k = 0; k < nx; ++k) Ao[nk * nx + k] = A[r + (size_t)nr * k];

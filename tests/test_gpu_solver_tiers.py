@@ -134,3 +134,35 @@ def test_information_sets_with_more_inputs_than_states(core):
     np.testing.assert_array_equal(S, S2)
     np.testing.assert_array_equal(m, m2)
     assert abs(S - S2).max() == 0 and np.ptp(S[:, 0, :]) > 0.2    # the third input's range [0.1, 0.4] shows in the spread
+
+
+def test_row_pruning_with_a_skewed_proposal_basis(core):
+    """lbmpc_sampler.EV_U / LV_U may be any invertible basis: with skewed, badly conditioned columns the rows of the
+    polytope in proposal coordinates (a . U_i) cancel to small numbers while the evaluated a . (U t) still rounds at
+    the scale |a||U||t| -- the pruning margin of pack_sampler is built from the latter.  Streams == oracle."""
+    P = fixtures.params_dict()
+    args = fixtures.sampler_args(P)
+    arr = {}
+    for name in ("EV", "LV"):
+        V = np.asarray(args[name + "_V"], dtype=np.float64)
+        U = np.array([[1.0, 0.999], [1e-3, 2e-3]]) if name == "EV" else np.array([[3.0, -2.999], [0.5, 0.5003]])
+        Tt = np.linalg.solve(U, V.T).T                 # proposal coordinates of the vertices: x = U t
+        arr[name] = (np.ascontiguousarray(U), Tt.min(0), Tt.max(0))
+    nx, nu = 2, 1
+    a = dict(EV_A=_abi.fcol(args["EV_A"]), EV_b=_abi.fcol(args["EV_b"]).ravel(), EV_lo=_abi.fcol(arr["EV"][1]), EV_hi=_abi.fcol(arr["EV"][2]),
+             LV_A=_abi.fcol(args["LV_A"]), LV_b=_abi.fcol(args["LV_b"]).ravel(), LV_lo=_abi.fcol(arr["LV"][1]), LV_hi=_abi.fcol(arr["LV"][2]),
+             B=_abi.fcol(np.reshape(args["B"], (nx, nu))), min_u_LV=_abi.fcol(np.ravel(args["min_u"])), max_u_LV=_abi.fcol(np.ravel(args["max_u"])),
+             EV_U=_abi.fcol(arr["EV"][0]), LV_U=_abi.fcol(arr["LV"][0]))
+    s = _abi.Sampler(nx=nx, nu=nu, nEV=a["EV_A"].shape[0], nLV=a["LV_A"].shape[0], **{k: _abi.dptr(v) for k, v in a.items()})
+    smp = _abi.Keep(s, a)
+    for N, batch, set0 in [(4000, 3, 0), (513, 2, 41)]:
+        S, m, st = core.sample_information_sets(smp, P["W_A"], N, batch, seed=17, set0=set0)
+        S2, m2, st2 = oracle_core.sample_information_sets(smp, P["W_A"], N, batch, seed=17, set0=set0)
+        np.testing.assert_array_equal(S, S2)
+        np.testing.assert_array_equal(m, m2)
+        np.testing.assert_array_equal(st, st2)
+    kw = dict(trials=200, steps=8, card_I0=10, seed=3, x0=[-12.0, 5.0], acc_bound=2.0, distance_error=15.0)
+    g, o = core.Context(P).mc_run(smp, **kw), oracle_core.Context(P).mc_run(smp, **kw)
+    for k in ("infeasible", "status", "qp_iters"):
+        np.testing.assert_array_equal(g[k], o[k], err_msg=k)
+    np.testing.assert_allclose(g["x_final"], o["x_final"], rtol=1e-9, atol=1e-12)

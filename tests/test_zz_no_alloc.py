@@ -81,3 +81,25 @@ def test_noalloc_rejects_beyond_the_static_scratch(env):
     dev.halfspace_max_noalloc(WA, d[:4500], out[:4500])
     dev.halfspace_max_noalloc(WA, d[4500:], out[4500:])
     assert torch.equal(out, ref)
+
+
+def test_noalloc_call_can_be_captured_in_a_graph_and_replayed(env):
+    """the callers this entry point is for include code under HIP graph capture: the call is captured on a side
+    stream (an allocation, a synchronisation or a copy from pageable memory inside it would abort the capture), the
+    graph is replayed on new sample values in the same buffers, and every replay equals the plain call"""
+    torch, core, dev = env
+    rng = np.random.default_rng(5)
+    WA = np.vstack([np.eye(2), -np.eye(2)]) * np.array([[1.0, 2.5]])
+    S, d = _sets(torch, rng, 9, 6000, 2)
+    out = torch.full((9, 4), float("nan"), dtype=torch.float64, device="cuda:0")
+    dev.halfspace_max_noalloc(WA, d, out)          # first call outside the capture (one-time work of the entry point)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        dev.halfspace_max_noalloc(WA, d, out)
+    for scale in (1.0, 0.25, 3.0):
+        d.copy_(torch.from_numpy(S * scale).to("cuda:0"))
+        out.fill_(float("nan"))
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, dev.halfspace_max(WA, d)), scale
