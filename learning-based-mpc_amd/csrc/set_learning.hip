@@ -319,11 +319,12 @@ namespace lbmpc {
 // (the card(I0) = 10 ... 100 of the closed-loop Monte-Carlo, one set per trial) take fewer, so that the lanes of a
 // wave are busy and one wave learns several sets.  NT: length of the proposal vector t (NX, or LBMPC_MAX_NU when the
 // input draw has more components than the state: nu > nx).
-template <int NX, int NT>
+template <int NX, int NT, bool SHARED /* several sets per wave (lps_arg < 64) */>
 __global__ __launch_bounds__(256) void sample_sets_kernel(const SmpPhases* __restrict__ desc_g, int nW,
                                                           int64_t N, int64_t batch, uint64_t seed, uint64_t set0,
-                                                          int max_attempts, int lps, double* __restrict__ samples_out,
+                                                          int max_attempts, int lps_arg, double* __restrict__ samples_out,
                                                           double* __restrict__ m_out, int* __restrict__ status_out) {
+    const int lps = SHARED ? lps_arg : LB_WAVE;
     __shared__ SmpPhases D;
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(desc_g);
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256) void sample_sets_kernel(const SmpPhases* __res
     const int spw = LB_WAVE / lps;   // sets per wave
     const int64_t wv = (int64_t)blockIdx.x * (blockDim.x / LB_WAVE) + (threadIdx.x / LB_WAVE);
     if (wv * spw >= batch) return;
-    const int64_t b = wv * spw + lane / lps;
+    const int64_t b = SHARED ? wv * spw + lane / lps : wv;
     const uint64_t set = set0 + (uint64_t)b;
     const int nr4 = D.nr4;
     double m[LBMPC_MAX_NW];
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(256) void sample_sets_kernel(const SmpPhases* __res
         att = take ? 0 : att + 1;
         ph = take ? (ph == 2 ? 0 : ph + 1) : ph;
     }
-    if (lps == LB_WAVE) {
+    if (!SHARED) {
         const bool anycap = __builtin_amdgcn_ballot_w64(cap) != 0;
 #pragma unroll
         for (int j = 0; j < LBMPC_MAX_NW; ++j)
@@ -547,7 +548,11 @@ int launch_sample_sets(int nx, int nu, const SmpPhases* d, int nW, int64_t N, in
     const int lps = lanes_per_set(N);
     const int64_t waves = (batch + (LB_WAVE / lps) - 1) / (LB_WAVE / lps);
     dim3 grid((unsigned)((waves + 3) / 4));
-#define LAUNCH_SS(NXV, NTV) hipLaunchKernelGGL((sample_sets_kernel<NXV, NTV>), grid, dim3(256), 0, st, d, nW, N, batch, seed, set0, max_attempts, lps, samples_out_dev, m_out_dev, status_out_dev)
+#define LAUNCH_SS(NXV, NTV)                                                                                                      \
+    do {                                                                                                                         \
+        if (lps < LB_WAVE) hipLaunchKernelGGL((sample_sets_kernel<NXV, NTV, true>), grid, dim3(256), 0, st, d, nW, N, batch, seed, set0, max_attempts, lps, samples_out_dev, m_out_dev, status_out_dev); \
+        else hipLaunchKernelGGL((sample_sets_kernel<NXV, NTV, false>), grid, dim3(256), 0, st, d, nW, N, batch, seed, set0, max_attempts, lps, samples_out_dev, m_out_dev, status_out_dev); \
+    } while (0)
     const bool wide = nu > nx;   // the input draw has more components than the state
     switch (nx) {
         case 1: if (wide) LAUNCH_SS(1, LBMPC_MAX_NU); else LAUNCH_SS(1, 1); break;

@@ -876,8 +876,9 @@ static int pick_gen_lanes(const lbmpc_ctx* c, int waves, int lanes_per_wave) {
     int cap = 32;
     if (const char* e = getenv("LBMPC_GEN_LANES")) { const int v = atoi(e); if (v >= 0 && v <= 64) cap = v; }
     const size_t base = c->lds_const_bytes + (size_t)waves * ws_doubles(c->h.nz) * 8 + MC_HIST_INTS * 4;
-    int gl = 64;
-    while (gl > cap || gl > lanes_per_wave) gl >>= 1;
+    int gl = 4;
+    while (gl < lanes_per_wave && gl < 64) gl <<= 1;   // the smallest power of two that holds the wave's trials ...
+    while (gl > cap) gl >>= 1;                          // ... up to the cap (more trials are served in groups)
     while (gl >= 4 && base + (size_t)waves * lanegen_doubles(gl) * 8 > LDS_LIMIT) gl >>= 1;
     return gl >= 4 ? gl : 0;
 }
@@ -995,14 +996,22 @@ static int mc_plan(const lbmpc_ctx* c, int64_t trials, int steps, McPlan* p) {
     const char* env_t = getenv("LBMPC_MC_T");
     // T = 2 trials per lane once 2-per-lane still fills every CU
     p->wide = env_t ? (atoi(env_t) == 2) : (trials >= (int64_t)256 * 8 * 128 * 2);
-    p->waves = pick_waves(c, 8);
-    if (!p->waves) { set_error("constants (%zu B) do not fit in LDS", c->lds_const_bytes); return LBMPC_ERR_DIM; }
     // trials per wave: 64 once that still gives every SIMD a wave of its own (1024 SIMDs, with some slack), else fewer
     // lanes per wave so that small batches spread over the chip (every solver tier costs per wave-trip, whatever the
-    // number of live lanes)
-    int tpw = 64;
+    // number of live lanes).  Batches so small that 8-wave blocks would leave a quarter of the CUs idle run as 4-wave
+    // blocks, one wave per SIMD, with the trials spread evenly (C3 as written, 10000 trials: 250 blocks of 4 x 10
+    // trials instead of 157 of 8 x 8: -8 %; tools/c3_shape_sweep.sh).  Any packing gives bitwise the same results.
+    int want_waves = 8, tpw = 64;
     while (tpw > 4 && (trials + tpw - 1) / tpw < 1088) tpw >>= 1;
-    if (const char* env_w = getenv("LBMPC_MC_TPW")) { const int v = atoi(env_w); if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) tpw = v; }
+    if ((trials + 8 * tpw - 1) / (8 * tpw) < 192) {
+        want_waves = 4;
+        tpw = (int)((trials + 1023) / 1024);
+        tpw = tpw < 4 ? 4 : tpw;
+    }
+    if (const char* env_wv = getenv("LBMPC_MC_WAVES")) { const int v = atoi(env_wv); if (v >= 1 && v <= 8) want_waves = v; }   // testing
+    if (const char* env_w = getenv("LBMPC_MC_TPW")) { const int v = atoi(env_w); if (v >= 1 && v <= 64) tpw = v; }
+    p->waves = pick_waves(c, want_waves);
+    if (!p->waves) { set_error("constants (%zu B) do not fit in LDS", c->lds_const_bytes); return LBMPC_ERR_DIM; }
     p->tpw = tpw;
     p->gen_lanes = pick_gen_lanes(c, p->waves, tpw);
     p->lds = block_lds_bytes(c, p->waves, p->gen_lanes);

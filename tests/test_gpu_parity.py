@@ -474,13 +474,14 @@ def test_mc_trials_per_wave_invariance(core, P, smp):
     kw = dict(trials=700, steps=9, card_I0=10, seed=13, x0=[-12.0, 5.0], acc_bound=2.0, distance_error=15.0, traj_trials=700)
     ref = ctx.mc_run(smp, **kw)          # automatic choice (4 per wave at this size)
     try:
-        for tpw in ("8", "32", "64"):
-            os.environ["LBMPC_MC_TPW"] = tpw
+        for tpw, waves in (("8", "8"), ("32", "8"), ("64", "8"), ("10", "4"), ("7", "6"), ("1", "8")):   # any packing, powers of two or not
+            os.environ["LBMPC_MC_TPW"], os.environ["LBMPC_MC_WAVES"] = tpw, waves
             got = ctx.mc_run(smp, **kw)
             for k in ref:
-                np.testing.assert_array_equal(ref[k], got[k], err_msg=f"{k} tpw={tpw}")
+                np.testing.assert_array_equal(ref[k], got[k], err_msg=f"{k} tpw={tpw} waves={waves}")
     finally:
         os.environ.pop("LBMPC_MC_TPW", None)
+        os.environ.pop("LBMPC_MC_WAVES", None)
     ctx.close()
 
 

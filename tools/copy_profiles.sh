@@ -2,7 +2,7 @@
 # copy the summaries of the last tools/profile_round.sh run (gpurun_out/round) into profiles/ under the round's prefix
 # ($1, e.g. r02); the per-dispatch counter csvs are cut down to the library's kernels
 cd "$(dirname "$0")/.."
-p=${1:-r02}; src=gpurun_out/round
+p=${1:-r03}; src=gpurun_out/round
 cp $src/bench.json profiles/${p}_bench_under_rocprof.json
 cp $src/kernel_stats.csv profiles/${p}_kernel_stats.csv
 cp $src/pmc_summary.json profiles/${p}_pmc_summary.json
