@@ -909,7 +909,12 @@ static int step_dev(lbmpc_ctx* c, int64_t batch, int uq, const StepIO& io, hipSt
         }                                                                                            \
         hipLaunchKernelGGL(uqmpc_step_kernel<NXV>, grid, blk, lds, st, c->d, batch, uq, gen_lanes, io); \
     } while (0)
-#ifdef LBMPC_DEV_FAST   // development build (Makefile `dev`): nx = 2, 3 only
+#ifdef LBMPC_DEV_NX4    // development build (Makefile `dev4`): nx = 4 only
+    switch (c->h.nx) {
+        case 4: LAUNCH_STEP(4); break;
+        default: set_error("development build: nx = 4 only"); return LBMPC_ERR_UNSUPPORTED;
+    }
+#elif defined(LBMPC_DEV_FAST)   // development build (Makefile `dev`): nx = 2, 3 only
     switch (c->h.nx) {
         case 2: LAUNCH_STEP(2); break;
         case 3: LAUNCH_STEP(3); break;
@@ -1048,7 +1053,9 @@ extern "C" int lbmpc_mc_plan(lbmpc_ctx* c, int64_t trials, int steps, int32_t* o
     McPlan p;
     if (int rc = mc_plan(c, trials, steps, &p)) return rc;
     int vg = 0, sc = 0, sl = 0, rc = 0;
-#ifdef LBMPC_DEV_FAST
+#ifdef LBMPC_DEV_NX4
+    rc = kern_attrs(mc_kernel<4, 1>, &vg, &sc, &sl);
+#elif defined(LBMPC_DEV_FAST)
     switch (c->h.nx) { case 2: rc = kern_attrs(mc_kernel<2, 1>, &vg, &sc, &sl); break; default: rc = kern_attrs(mc_kernel<3, 1>, &vg, &sc, &sl); break; }
 #else
     switch (c->h.nx * 2 + (p.wide ? 1 : 0)) {
@@ -1200,7 +1207,13 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
         if (int rc = allow_lds(mc_kernel<NXV, TV>, lds)) return rc;                             \
         hipLaunchKernelGGL((mc_kernel<NXV, TV>), grid, blk, lds, st, c->d, a);                  \
     } while (0)
-#ifdef LBMPC_DEV_FAST
+#ifdef LBMPC_DEV_NX4
+#define LAUNCH_MC_ALL()                                                                         \
+    switch (c->h.nx * 2 + (wide ? 1 : 0)) {                                                     \
+        case 8: LAUNCH_MC(4, 1); break;                                                         \
+        default: set_error("development build: nx = 4, one trial per lane"); return LBMPC_ERR_UNSUPPORTED; \
+    }
+#elif defined(LBMPC_DEV_FAST)
 #define LAUNCH_MC_ALL()                                                                         \
     switch (c->h.nx * 2 + (wide ? 1 : 0)) {                                                     \
         case 4: LAUNCH_MC(2, 1); break;                                                         \

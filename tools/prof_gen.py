@@ -8,6 +8,8 @@ from lbmpc import core, params, _abi
 LEG = os.environ.get("LEG", "C1")
 if LEG == "C1":
     P = params.load(os.path.join(ROOT, "tests", "golden", "params_2x2.npz")); x0 = [-12.0, 5.0]; trials, K, card, seed = 65536, 50, 100, 1
+elif LEG == "C4t":   # build: make prof4
+    P = params.load("4x4"); x0 = [-12.0, 5.0, 0.0, 0.0]; trials, K, card, seed = 131072, 32, 10, 4
 else:
     P = params.load("3x3"); x0 = None; trials, K, card, seed = 10000, 20, 10, 5
 trials = int(os.environ.get("TRIALS", trials))
@@ -32,6 +34,9 @@ print(LEG, "waves*ticks total %.3e; slowest wave %.3e ticks" % (tot, v[7]))
 for i, n in enumerate(["uq+tighten", "first_pass(ellipsoid)", "heavy region (filter + solves)", "dynamics"]):
     print(f"  {n:32s} {v[i]/tot*100:6.2f} %")
 print("  heavy region: S-lane tier %.1f %%  general lane tier %.1f %%  row tier %.1f %% of total" % (v[32] / tot * 100, v[33] / tot * 100, v[34] / tot * 100))
+ls = v[8:14]
+print("  S-lane tier: scans %.1f %%  step 2 %.1f %%  step 1 other %.1f %% of total; %.0f ticks per scan pass, %.0f step-2 ticks per trip, %.0f step-1 ticks per trip"
+      % (ls[0] / tot * 100, ls[1] / tot * 100, ls[2] / tot * 100, ls[0] / max(ls[5], 1), ls[1] / max(ls[4], 1), ls[2] / max(ls[4], 1)))
 g = v[24:32]
 names = ["step1 candidates", "scans", "new pivot (row, g, cg)", "rhs + solves", "zd (Wm' r)", "ratio test + update", "append", "drop + rebuild"]
 gt = g.sum()

@@ -36,7 +36,19 @@ __global__ void rate(unsigned long long* o, long long* cyc, int iters, unsigned 
             asm volatile("v_xor_b32 %0, %8, %0\n v_xor_b32 %1, %8, %1\n v_xor_b32 %2, %8, %2\n v_xor_b32 %3, %8, %3\n"
                          "v_xor_b32 %4, %8, %4\n v_xor_b32 %5, %8, %5\n v_xor_b32 %6, %8, %6\n v_xor_b32 %7, %8, %7\n"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(M));
-        } else {                  // v_mul_u32_u24
+        } else if (MODE == 6) {   // v_pk_fma_f32 (two fp32 fma per lane)
+            asm volatile("v_pk_fma_f32 %0, %8, %8, %0\n v_pk_fma_f32 %1, %8, %8, %1\n v_pk_fma_f32 %2, %8, %8, %2\n v_pk_fma_f32 %3, %8, %8, %3\n"
+                         "v_pk_fma_f32 %4, %8, %8, %4\n v_pk_fma_f32 %5, %8, %8, %5\n v_pk_fma_f32 %6, %8, %8, %6\n v_pk_fma_f32 %7, %8, %8, %7\n"
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(c));
+        } else if (MODE == 7) {   // v_fma_f32
+            asm volatile("v_fma_f32 %0, %8, %8, %0\n v_fma_f32 %1, %8, %8, %1\n v_fma_f32 %2, %8, %8, %2\n v_fma_f32 %3, %8, %8, %3\n"
+                         "v_fma_f32 %4, %8, %8, %4\n v_fma_f32 %5, %8, %8, %5\n v_fma_f32 %6, %8, %8, %6\n v_fma_f32 %7, %8, %8, %7\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(M));
+        } else if (MODE == 8) {   // v_min_f64
+            asm volatile("v_min_f64 %0, %8, %0\n v_min_f64 %1, %8, %1\n v_min_f64 %2, %8, %2\n v_min_f64 %3, %8, %3\n"
+                         "v_min_f64 %4, %8, %4\n v_min_f64 %5, %8, %5\n v_min_f64 %6, %8, %6\n v_min_f64 %7, %8, %7\n"
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(c));
+        } else if (MODE == 5) {   // v_mul_u32_u24
             asm volatile("v_mul_u32_u24 %0, %8, %0\n v_mul_u32_u24 %1, %8, %1\n v_mul_u32_u24 %2, %8, %2\n v_mul_u32_u24 %3, %8, %3\n"
                          "v_mul_u32_u24 %4, %8, %4\n v_mul_u32_u24 %5, %8, %5\n v_mul_u32_u24 %6, %8, %6\n v_mul_u32_u24 %7, %8, %7\n"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(M));
@@ -50,12 +62,12 @@ __global__ void rate(unsigned long long* o, long long* cyc, int iters, unsigned 
 
 int main() {
     const int iters = 4000;
-    const char* names[] = {"v_mad_u64_u32", "v_mul_hi_u32", "v_mul_lo_u32", "v_fma_f64", "v_xor_b32", "v_mul_u32_u24"};
+    const char* names[] = {"v_mad_u64_u32", "v_mul_hi_u32", "v_mul_lo_u32", "v_fma_f64", "v_xor_b32", "v_mul_u32_u24", "v_pk_fma_f32", "v_fma_f32", "v_min_f64"};
     for (int wps : {1, 2, 4, 8}) {   // waves per SIMD: blocks of 256 threads (one wave per SIMD each), wps blocks per CU
         const int blocks = 256 * wps, threads = 256, nw = blocks * threads / 64;
         unsigned long long* o; long long* cyc;
         CK(hipMalloc(&o, (size_t)blocks * threads * 8)); CK(hipMalloc(&cyc, (size_t)nw * 8));
-        for (int mode = 0; mode < 6; ++mode) {
+        for (int mode = 0; mode < 9; ++mode) {
             hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
             for (int rep = 0; rep < 2; ++rep) {
                 CK(hipEventRecord(e0));
@@ -65,7 +77,10 @@ int main() {
                     case 2: hipLaunchKernelGGL(rate<2>, dim3(blocks), dim3(threads), 0, 0, o, cyc, iters, 1u); break;
                     case 3: hipLaunchKernelGGL(rate<3>, dim3(blocks), dim3(threads), 0, 0, o, cyc, iters, 1u); break;
                     case 4: hipLaunchKernelGGL(rate<4>, dim3(blocks), dim3(threads), 0, 0, o, cyc, iters, 1u); break;
-                    default: hipLaunchKernelGGL(rate<5>, dim3(blocks), dim3(threads), 0, 0, o, cyc, iters, 1u); break;
+                    case 5: hipLaunchKernelGGL(rate<5>, dim3(blocks), dim3(threads), 0, 0, o, cyc, iters, 1u); break;
+                    case 6: hipLaunchKernelGGL(rate<6>, dim3(blocks), dim3(threads), 0, 0, o, cyc, iters, 1u); break;
+                    case 7: hipLaunchKernelGGL(rate<7>, dim3(blocks), dim3(threads), 0, 0, o, cyc, iters, 1u); break;
+                    default: hipLaunchKernelGGL(rate<8>, dim3(blocks), dim3(threads), 0, 0, o, cyc, iters, 1u); break;
                 }
                 CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             }
