@@ -524,6 +524,8 @@ typedef struct orc_ctx {
     double Wb[LBMPC_MAX_NW];
     int pr[LBMPC_MAX_NX], qr[LBMPC_MAX_NX];
     double ic[LBMPC_MAX_NW];
+    int hasE;                       /* orc_set_certificate: benchmark variant only (see step_one) */
+    double ME[LBMPC_MAX_NX * LBMPC_MAX_NX];
 } orc_ctx;
 
 static int invert_spd_like(int n, const double* M /* row-major */, double* Minv) {
@@ -609,6 +611,19 @@ int orc_uqmpc_create(const lbmpc_params* p, orc_ctx** out) {
     int rc = orc_box_structure(p->W_A, c->nW, nx, c->pr, c->qr, c->ic);
     if (rc) { free(c->SA); free(c->Sb); free(c->H); free(c); return rc; }
     *out = c;
+    return 0;
+}
+
+/* Benchmark variant of the closed loop (bench.py: cpu_baseline.with_certificate), off unless this is called: ME is
+ * the matrix of an ellipsoid {x : x' ME x <= 1} INSIDE S (the caller computes it; the HIP library uses the same
+ * kind of certificate, uqmpc.hip inscribed_ellipsoid).  Then q' ME q <= (alpha (1 - 1e-6))^2 proves that no S row is
+ * violated at z = 0 (Cauchy-Schwarz), and with min(1 - h_k) >= 0 no H row is, so qp_solve would return z = 0 with an
+ * empty active set after one scan of all rows: step_one skips the solve.  The parity tests never set it: the
+ * oracle they check against evaluates every row.  ME = NULL switches it off. */
+int orc_set_certificate(orc_ctx* c, const double* ME_rowmajor) {
+    if (!c) return LBMPC_ERR_ARG;
+    c->hasE = ME_rowmajor != NULL;
+    for (int i = 0; i < c->nx * c->nx; ++i) c->ME[i] = ME_rowmajor ? ME_rowmajor[i] : 0.0;
     return 0;
 }
 
@@ -861,7 +876,16 @@ static int step_one(const orc_ctx* c, int uq_update, const double* x, double alp
     for (int k = 0; k < nx; ++k) q[k] = beta * Tv[k] - x[k];
     double z[LBMPC_MAX_NZ], lam[LBMPC_MAX_NZ];
     int act[LBMPC_MAX_NZ], nact = 0, iters = 0;
-    int st = qp_solve(c, q, alpha, omh, z, act, lam, &nact, &iters, hint, nhint ? *nhint : 0);
+    int st = 0, certified = 0;
+    if (c->hasE) { /* benchmark variant (orc_set_certificate): z = 0 is optimal when no row is violated there */
+        double acc = 0.0, mo = omh[0];
+        for (int a = 0; a < nx; ++a) for (int b = 0; b < nx; ++b) acc += q[a] * c->ME[a * nx + b] * q[b];
+        for (int r = 1; r < c->nc; ++r) if (omh[r] < mo) mo = omh[r];
+        const double rad = alpha * (1.0 - 1e-6);
+        certified = alpha > 0.0 && acc <= rad * rad && mo >= 0.0;
+    }
+    if (certified) for (int k = 0; k < nz; ++k) z[k] = 0.0;   /* what qp_solve returns after one scan: nact = iters = 0 */
+    else st = qp_solve(c, q, alpha, omh, z, act, lam, &nact, &iters, hint, nhint ? *nhint : 0);
     if (hint && nhint) { for (int a = 0; a < nact; ++a) hint[a] = act[a]; *nhint = nact; }
     if (st > status) status = st;
     if (s0) memcpy(s0, z, sizeof(double) * nx);

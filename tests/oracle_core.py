@@ -143,6 +143,17 @@ class Context:
             o = {k: (v[0] if isinstance(v, np.ndarray) else v) for k, v in o.items()}
         return o
 
+    def set_certificate(self, ME=None):
+        """benchmark variant only (orc_set_certificate): skip the QP when the inscribed ellipsoid {x' ME x <= 1} of S
+        proves z = 0 optimal; None switches it off"""
+        if ME is None:
+            rc = self.lib.orc_set_certificate(self.handle, None)
+        else:
+            m = np.ascontiguousarray(ME, dtype=np.float64)
+            assert m.shape == (self.nx, self.nx)
+            rc = self.lib.orc_set_certificate(self.handle, m.ctypes.data_as(C.POINTER(C.c_double)))
+        assert rc == 0, rc
+
     def mc_run(self, sampler, trials, steps, card_I0, seed, x0, acc_bound, distance_error, trial0=0, traj_trials=0,
                sampler_max_attempts=1000, threads=1):
         """threads > 1: the trials are spread over that many host threads (OpenMP); same results"""

@@ -27,5 +27,7 @@ def load():
         lib.orc_ctx_export.restype = ci
         lib.orc_mc_run_omp.argtypes = [C.c_void_p, C.POINTER(_abi.Sampler), C.POINTER(_abi.McCfg), C.POINTER(_abi.McOut), ci]
         lib.orc_mc_run_omp.restype = ci
+        lib.orc_set_certificate.argtypes = [C.c_void_p, dp]
+        lib.orc_set_certificate.restype = ci
         _lib = lib
     return _lib
