@@ -38,7 +38,7 @@ extern "C" {
 #define LBMPC_ERR_ARG (-1)         /* null pointer / negative size / inconsistent dims      */
 #define LBMPC_ERR_DIM (-2)         /* dimension beyond the compiled limits below            */
 #define LBMPC_ERR_HIP (-3)         /* a HIP runtime call failed (see lbmpc_last_error)      */
-#define LBMPC_ERR_UNSUPPORTED (-4) /* e.g. prior W that is not an axis-aligned box          */
+#define LBMPC_ERR_UNSUPPORTED (-4) /* e.g. an option the build or the kernel shape lacks      */
 #define LBMPC_ERR_NODEVICE (-5)    /* no gfx950 device visible                              */
 
 /* numerical statuses (also the per-trial / per-problem status words) */
@@ -184,8 +184,8 @@ int lbmpc_sample_polytope(const double* XA, const double* Xb, int nr, int nx, co
  * alpha is unique; y is not (SURVEY.md hard part 1): tiebreak LBMPC_TIE_CENTER returns, for an axis-aligned box W
  * (every reference configuration), the midpoint of each coordinate's optimal interval (closed form), and for any other
  * bounded polytope W (nx+1 <= nW <= 16) the mean of the feasible basic solutions of the optimal face (vertex
- * enumeration, one lane per LP: C(2nW+2, nx+1) small solves, meant for set learning, not for the closed loop, whose
- * controllers take box priors only); the two coincide on a box.
+ * enumeration, one lane per LP: C(2nW+2, nx+1) small solves; the closed loop uses the same routine for the steps in
+ * which the new disturbance falls outside the current set, see lbmpc_uqmpc_create); the two coincide on a box.
  * active_mask (batch x uint32, may be NULL): box W: bit k set if axis k attains alpha (k < nx); general W: bit j set if
  * row j of W binds on either side.
  * status (batch ints, may be NULL): LBMPC_ST_LP_INFEASIBLE where the LP has no feasible point (some m_j > Wb_j). */
@@ -228,7 +228,12 @@ typedef struct lbmpc_ctx lbmpc_ctx;
 
 /* Build the device-resident constant block (constraint matrix [-S_A 0; F_bar Psi^i], (2P)^-1,
  * T = (I-Phi)^-1, F_Com T, S_A T ...).  Replaces the constructors UQRobustMPC.m:39-66 /
- * NominalRobustMPC.m:28-45 (which build CasADi Opti objects). *ctx_out = NULL on error. */
+ * NominalRobustMPC.m:28-45 (which build CasADi Opti objects). *ctx_out = NULL on error.
+ * The prior W may be any bounded polytope (UQRobustMPC.m:124-139 takes any W): an axis-aligned box (nW = 2 nx, every
+ * reference configuration) gets the closed-form set update; any other W with nx+1 <= nW <= 16 rows gets the
+ * vertex-enumeration LP of lbmpc_homothety_lp, W_hat rows in the caller's order (LBMPC_ERR_DIM outside that range).
+ * Such contexts run lbmpc_uqmpc_step, lbmpc_mc_run and lbmpc_multi_* like box contexts, one trial per lane and
+ * without the steady-state kernel (written for a box). */
 int lbmpc_uqmpc_create(const lbmpc_params* p, lbmpc_ctx** ctx_out);
 void lbmpc_destroy(lbmpc_ctx* ctx);
 

@@ -240,7 +240,16 @@ __global__ __launch_bounds__(256) void uqmpc_step_kernel(const CtxDev* __restric
 #pragma unroll
         for (int k = 0; k < NX; ++k) { x[k] = io.x[bb * NX + k]; v[k] = io.v_prev[bb * NX + k]; w[k] = (uq && io.w_new) ? io.w_new[bb * NX + k] : 0.0; }
         alpha[0] = io.alpha_prev[bb];
-        if (uq) status = uq_update<NX>(C, alpha[0], v, w, bh);
+        if (C->genW) {   // general-polytope prior: out of line (uqmpc_dev.hpp)
+            double v4[LBMPC_MAX_NX] = {0.0, 0.0, 0.0, 0.0}, w4[LBMPC_MAX_NX] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < NX; ++k) { v4[k] = v[k]; w4[k] = w[k]; }
+            const UqRes r = genw_uq_update(C, uq, alpha[0], v4[0], v4[1], v4[2], v4[3], w4[0], w4[1], w4[2], w4[3],
+                                           (valid && io.Wb_hat) ? io.Wb_hat + b * C->gw.nW : nullptr);
+            alpha[0] = r.alpha; status = r.st;
+#pragma unroll
+            for (int k = 0; k < NX; ++k) v[k] = r.v[k];
+        } else if (uq) status = uq_update<NX>(C, alpha[0], v, w, bh);
         else w_hat_b<NX>(C, alpha[0], v, bh);
         tighten<NX>(C, alpha[0], v, x, q[0], momh[0], aomh[0]);
         first_pass<NX, 1>(C, L, alpha, q, momh, need);
@@ -271,7 +280,7 @@ __global__ __launch_bounds__(256) void uqmpc_step_kernel(const CtxDev* __restric
         if (io.alpha) io.alpha[b] = alpha[0];
         if (io.v) for (int k = 0; k < NX; ++k) io.v[b * NX + k] = v[k];
         if (io.hk) for (int r = 0; r < C->nc; ++r) io.hk[b * C->nc + r] = hk_value<NX>(C, alpha[0], v, r);
-        if (io.Wb_hat)
+        if (io.Wb_hat && !C->genW)
 #pragma unroll
             for (int r = 0; r < 2 * NX; ++r) io.Wb_hat[b * 2 * NX + C->box.perm[r]] = bh[r];
         if (io.Sb_hat) {  // S_hat = alpha S + (1-alpha) T v   (UQRobustMPC.m:76)
@@ -309,7 +318,11 @@ __device__ unsigned long long lbmpc_prof_wave[3 * 4096];  // per wave: lifetime,
 #define PROF_ADD(slot, t0, t1)
 #endif
 
-template <int NX, int T>
+// GW: the instantiation carries the set update for a general-polytope prior W (CtxDev::genW) beside the box form.
+// Box contexts use GW = false except for nx = 4, where the instantiation WITH the out-of-line branch measured 3.5 %
+// faster on the C4 transient (4.22 -> 4.07 ms, same-box A/B) and 2 % slower on C1 (nx = 2): register allocation luck
+// either way, taken where it helps.
+template <int NX, int T, bool GW>
 __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, McArgs a) {
     extern __shared__ double lds[];
     double* ws_base;
@@ -359,12 +372,20 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, M
             if (a.resume) continue;   // state arrives at step kpos
             // initial set learning: InitialSetComputation.solve (:48-59).  The maxima over the card_I0 samples come from
             // the pre-pass (sample_sets_kernel: lanes walk their own draws instead of waiting for the wave's slowest)
-            double m[2 * NX];
-#pragma unroll
-            for (int r = 0; r < 2 * NX; ++r) m[r] = a.m0[cl[t] * (2 * NX) + r];
             { const int s0i = a.i0_status[cl[t]]; status[t] = s0i > status[t] ? s0i : status[t]; }
-            uint32_t mask;
-            int st = homothety_box<NX>(&C->box, m, alpha[t], v[t], mask);
+            int st;
+            if (GW && C->genW) {
+                const UqRes r = genw_initial(C, a.m0 + cl[t] * C->gw.nW);
+                alpha[t] = r.alpha; st = r.st;
+#pragma unroll
+                for (int k = 0; k < NX; ++k) v[t][k] = r.v[k];
+            } else {
+                double m[2 * NX];
+#pragma unroll
+                for (int r = 0; r < 2 * NX; ++r) m[r] = a.m0[cl[t] * (2 * NX) + r];
+                uint32_t mask;
+                st = homothety_box<NX>(&C->box, m, alpha[t], v[t], mask);
+            }
             status[t] = st > status[t] ? st : status[t];
 #pragma unroll
             for (int k = 0; k < NX; ++k) {
@@ -418,7 +439,16 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, M
                 PROF_T(pa);
                 double bh[2 * NX];
                 bool changed = false;
-                int st = uq_update<NX>(C, alpha[t], v[t], wst[t], bh, &changed);  // w_new = 0 at k = 0 (Case_3...:62-65)
+                int st;
+                if (GW && C->genW) {
+                    double v4[LBMPC_MAX_NX] = {0.0, 0.0, 0.0, 0.0}, w4[LBMPC_MAX_NX] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) { v4[i] = v[t][i]; w4[i] = wst[t][i]; }
+                    const UqRes r = genw_uq_update(C, 1, alpha[t], v4[0], v4[1], v4[2], v4[3], w4[0], w4[1], w4[2], w4[3], nullptr);
+                    alpha[t] = r.alpha; st = r.st; changed = r.changed != 0;
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) v[t][i] = r.v[i];
+                } else st = uq_update<NX>(C, alpha[t], v[t], wst[t], bh, &changed);  // w_new = 0 at k = 0 (Case_3...:62-65)
                 status[t] = st > status[t] ? st : status[t];
                 PROF_T(pb);
                 // (1-alpha) T v and min(1 - h_k) only move when the set update moved (alpha, v): kept between steps
@@ -750,7 +780,15 @@ extern "C" int lbmpc_uqmpc_create(const lbmpc_params* p, lbmpc_ctx** out) {
     lbmpc_ctx* c = new lbmpc_ctx();
     CtxDev& h = c->h;
     std::memset(&h, 0, sizeof(h));
-    if (int rc = pack_box(p->W_A, p->W_b, p->nW, nx, &h.box)) { delete c; return rc; }
+    if (int rc = pack_box(p->W_A, p->W_b, p->nW, nx, &h.box)) {
+        // not an axis-aligned box: the set update solves LPforUQ by vertex enumeration (UQRobustMPC.m:124-139 takes any W)
+        if (rc != LBMPC_ERR_UNSUPPORTED) { delete c; return rc; }
+        if (p->nW < nx + 1 || p->nW > LBMPC_MAX_NW) { set_error("lbmpc_uqmpc_create: general W needs nx+1 <= nW <= %d", LBMPC_MAX_NW); delete c; return LBMPC_ERR_DIM; }
+        std::memset(&h.box, 0, sizeof(h.box));
+        h.genW = 1;
+        h.gw.nW = p->nW; h.gw.nx = nx;
+        for (int j = 0; j < p->nW; ++j) { for (int k = 0; k < nx; ++k) h.gw.WA[j * nx + k] = CMX(p->W_A, p->nW, j, k); h.gw.Wb[j] = p->W_b[j]; }
+    }
     h.nx = nx; h.nu = nu; h.N = N; h.nc = nc; h.Nu = p->Nu; h.nS = nS; h.nW = p->nW; h.nz = nz; h.nH = nH;
     h.RL = nx + 1;              // [S_b, S_A row]; chunks of 4 rows are read as double2 broadcasts
     h.nSp = (nS + 127) & ~127;  // pad rows can never be violated
@@ -1001,6 +1039,7 @@ static int mc_plan(const lbmpc_ctx* c, int64_t trials, int steps, McPlan* p) {
     const char* env_t = getenv("LBMPC_MC_T");
     // T = 2 trials per lane once 2-per-lane still fills every CU
     p->wide = env_t ? (atoi(env_t) == 2) : (trials >= (int64_t)256 * 8 * 128 * 2);
+    if (c->h.genW) p->wide = false;   // the two-trials-per-lane instantiations carry the box set update only
     // trials per wave: 64 once that still gives every SIMD a wave of its own (1024 SIMDs, with some slack), else fewer
     // lanes per wave so that small batches spread over the chip (every solver tier costs per wave-trip, whatever the
     // number of live lanes).  Batches so small that 8-wave blocks would leave a quarter of the CUs idle run as 4-wave
@@ -1054,19 +1093,24 @@ extern "C" int lbmpc_mc_plan(lbmpc_ctx* c, int64_t trials, int steps, int32_t* o
     if (int rc = mc_plan(c, trials, steps, &p)) return rc;
     int vg = 0, sc = 0, sl = 0, rc = 0;
 #ifdef LBMPC_DEV_NX4
-    rc = kern_attrs(mc_kernel<4, 1>, &vg, &sc, &sl);
+    rc = kern_attrs(mc_kernel<4, 1, true>, &vg, &sc, &sl);
 #elif defined(LBMPC_DEV_FAST)
-    switch (c->h.nx) { case 2: rc = kern_attrs(mc_kernel<2, 1>, &vg, &sc, &sl); break; default: rc = kern_attrs(mc_kernel<3, 1>, &vg, &sc, &sl); break; }
+    switch (c->h.nx * 2 + (c->h.genW ? 1 : 0)) {
+        case 4: rc = kern_attrs(mc_kernel<2, 1, false>, &vg, &sc, &sl); break;
+        case 5: rc = kern_attrs(mc_kernel<2, 1, true>, &vg, &sc, &sl); break;
+        case 6: rc = kern_attrs(mc_kernel<3, 1, false>, &vg, &sc, &sl); break;
+        default: rc = kern_attrs(mc_kernel<3, 1, true>, &vg, &sc, &sl); break;
+    }
 #else
     switch (c->h.nx * 2 + (p.wide ? 1 : 0)) {
-        case 2: rc = kern_attrs(mc_kernel<1, 1>, &vg, &sc, &sl); break;
-        case 3: rc = kern_attrs(mc_kernel<1, 2>, &vg, &sc, &sl); break;
-        case 4: rc = kern_attrs(mc_kernel<2, 1>, &vg, &sc, &sl); break;
-        case 5: rc = kern_attrs(mc_kernel<2, 2>, &vg, &sc, &sl); break;
-        case 6: rc = kern_attrs(mc_kernel<3, 1>, &vg, &sc, &sl); break;
-        case 7: rc = kern_attrs(mc_kernel<3, 2>, &vg, &sc, &sl); break;
-        case 8: rc = kern_attrs(mc_kernel<4, 1>, &vg, &sc, &sl); break;
-        default: rc = kern_attrs(mc_kernel<4, 2>, &vg, &sc, &sl); break;
+        case 2: rc = c->h.genW ? kern_attrs(mc_kernel<1, 1, true>, &vg, &sc, &sl) : kern_attrs(mc_kernel<1, 1, false>, &vg, &sc, &sl); break;
+        case 3: rc = kern_attrs(mc_kernel<1, 2, false>, &vg, &sc, &sl); break;
+        case 4: rc = c->h.genW ? kern_attrs(mc_kernel<2, 1, true>, &vg, &sc, &sl) : kern_attrs(mc_kernel<2, 1, false>, &vg, &sc, &sl); break;
+        case 5: rc = kern_attrs(mc_kernel<2, 2, false>, &vg, &sc, &sl); break;
+        case 6: rc = c->h.genW ? kern_attrs(mc_kernel<3, 1, true>, &vg, &sc, &sl) : kern_attrs(mc_kernel<3, 1, false>, &vg, &sc, &sl); break;
+        case 7: rc = kern_attrs(mc_kernel<3, 2, false>, &vg, &sc, &sl); break;
+        case 8: rc = kern_attrs(mc_kernel<4, 1, true>, &vg, &sc, &sl); break;
+        default: rc = kern_attrs(mc_kernel<4, 2, false>, &vg, &sc, &sl); break;
     }
 #endif
     if (rc) return rc;
@@ -1158,14 +1202,15 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
         if (c->m0) LB_HIP(hipFree(c->m0));
         if (c->i0_status) LB_HIP(hipFree(c->i0_status));
         c->m0 = nullptr; c->i0_status = nullptr; c->m0_n = 0;
-        LB_HIP(hipMalloc((void**)&c->m0, (size_t)chunk * 2 * c->h.nx * sizeof(double)));
+        LB_HIP(hipMalloc((void**)&c->m0, (size_t)chunk * LBMPC_MAX_NW * sizeof(double)));   // 2 nx rows (box) or nW <= 16 (general W)
         LB_HIP(hipMalloc((void**)&c->i0_status, (size_t)chunk * sizeof(int)));
         c->m0_n = (size_t)chunk;
     }
     if (!c->smp_ph) LB_HIP(hipMalloc((void**)&c->smp_ph, sizeof(SmpPhases)));
     {
         SmpPhases hp;
-        pack_sample_phases(sd, c->h.box.WA, 2 * c->h.nx, &hp);   // rows in the canonical order of the box
+        if (c->h.genW) pack_sample_phases(sd, c->h.gw.WA, c->h.gw.nW, &hp);   // rows in the caller's order
+        else pack_sample_phases(sd, c->h.box.WA, 2 * c->h.nx, &hp);           // rows in the canonical order of the box
         LB_HIP(hipMemcpyAsync(c->smp_ph, &hp, sizeof(SmpPhases), hipMemcpyHostToDevice, st));   // pageable source: staged before the call returns
     }
     a.m0 = c->m0; a.i0_status = c->i0_status;
@@ -1176,7 +1221,7 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
         a.chunk0 = c0; a.chunk_n = cn;
         LB_HIP(hipMemsetAsync(a.nhint, 0, (size_t)cn * sizeof(int), st));
         // information-set pre-pass: set (seed, trial) of card_I0 samples per trial, attempt cap 100 (InitialSetComputation.m:108)
-        if (int rc = launch_sample_sets(c->h.nx, c->h.nu, c->smp_ph, 2 * c->h.nx, cfg->card_I0, cn, cfg->seed, (uint64_t)(cfg->trial0 + c0), 100,
+        if (int rc = launch_sample_sets(c->h.nx, c->h.nu, c->smp_ph, c->h.genW ? c->h.gw.nW : 2 * c->h.nx, cfg->card_I0, cn, cfg->seed, (uint64_t)(cfg->trial0 + c0), 100,
                                         nullptr, c->m0, c->i0_status, st)) return rc;
         if (cfg->steps > 0) {
             LB_HIP(hipMemsetAsync(c->xi_status, 0, (size_t)cn * sizeof(int), st));
@@ -1202,35 +1247,38 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
             }
             a.park = c->park;
         }
-#define LAUNCH_MC(NXV, TV)                                                                      \
+#define LAUNCH_MC_GW(NXV, TV, GWV)                                                              \
     do {                                                                                        \
-        if (int rc = allow_lds(mc_kernel<NXV, TV>, lds)) return rc;                             \
-        hipLaunchKernelGGL((mc_kernel<NXV, TV>), grid, blk, lds, st, c->d, a);                  \
+        if (int rc = allow_lds(mc_kernel<NXV, TV, GWV>, lds)) return rc;                        \
+        hipLaunchKernelGGL((mc_kernel<NXV, TV, GWV>), grid, blk, lds, st, c->d, a);             \
     } while (0)
+// one trial per lane: GW instantiation for a general W, and for nx = 4 always (see mc_kernel)
+#define LAUNCH_MC1(NXV, BOXGW)                                                                  \
+    do { if (c->h.genW || BOXGW) LAUNCH_MC_GW(NXV, 1, true); else LAUNCH_MC_GW(NXV, 1, false); } while (0)
 #ifdef LBMPC_DEV_NX4
 #define LAUNCH_MC_ALL()                                                                         \
     switch (c->h.nx * 2 + (wide ? 1 : 0)) {                                                     \
-        case 8: LAUNCH_MC(4, 1); break;                                                         \
+        case 8: LAUNCH_MC_GW(4, 1, true); break;                                                \
         default: set_error("development build: nx = 4, one trial per lane"); return LBMPC_ERR_UNSUPPORTED; \
     }
 #elif defined(LBMPC_DEV_FAST)
 #define LAUNCH_MC_ALL()                                                                         \
     switch (c->h.nx * 2 + (wide ? 1 : 0)) {                                                     \
-        case 4: LAUNCH_MC(2, 1); break;                                                         \
-        case 6: LAUNCH_MC(3, 1); break;                                                         \
+        case 4: LAUNCH_MC1(2, false); break;                                                    \
+        case 6: LAUNCH_MC1(3, false); break;                                                    \
         default: set_error("development build: nx = 2, 3, one trial per lane"); return LBMPC_ERR_UNSUPPORTED; \
     }
 #else
 #define LAUNCH_MC_ALL()                                                                         \
     switch (c->h.nx * 2 + (wide ? 1 : 0)) {                                                     \
-        case 2: LAUNCH_MC(1, 1); break;                                                         \
-        case 3: LAUNCH_MC(1, 2); break;                                                         \
-        case 4: LAUNCH_MC(2, 1); break;                                                         \
-        case 5: LAUNCH_MC(2, 2); break;                                                         \
-        case 6: LAUNCH_MC(3, 1); break;                                                         \
-        case 7: LAUNCH_MC(3, 2); break;                                                         \
-        case 8: LAUNCH_MC(4, 1); break;                                                         \
-        default: LAUNCH_MC(4, 2); break;                                                        \
+        case 2: LAUNCH_MC1(1, false); break;                                                    \
+        case 3: LAUNCH_MC_GW(1, 2, false); break;                                               \
+        case 4: LAUNCH_MC1(2, false); break;                                                    \
+        case 5: LAUNCH_MC_GW(2, 2, false); break;                                               \
+        case 6: LAUNCH_MC1(3, false); break;                                                    \
+        case 7: LAUNCH_MC_GW(3, 2, false); break;                                               \
+        case 8: LAUNCH_MC_GW(4, 1, true); break;                                                \
+        default: LAUNCH_MC_GW(4, 2, false); break;                                              \
     }
 #endif
         a.kseg0 = 0; a.kseg1 = ksplit; a.resume = 0;
@@ -1244,7 +1292,8 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
             LAUNCH_MC_ALL();   // trials whose saved step is before the horizon's end (all of them without the lean kernel)
         }
 #undef LAUNCH_MC_ALL
-#undef LAUNCH_MC
+#undef LAUNCH_MC1
+#undef LAUNCH_MC_GW
         LB_HIP(hipGetLastError());
     }
     return 0;

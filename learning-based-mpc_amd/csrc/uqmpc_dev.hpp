@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "homothety_gen.hpp"
 
 namespace lbmpc {
 
@@ -27,6 +28,8 @@ struct CtxDev {
     double FcT[LBMPC_MAX_NC * LBMPC_MAX_NX];  // (F+GK) T row-major
     double hs[LBMPC_MAX_NC];
     BoxW box;
+    int genW;            // 1: W is not an axis-aligned box: the set update solves the LP by vertex enumeration (gw; box is unused)
+    GenW gw;
     const double* Srow;  // nSp x RL : [S_b[j], S_A[j,0..nx-1]], RL = nx + 1
     const float* S32;    // fp32 copy for the first-pass filter, row PAIRS interleaved: [b_j b_j+1 a_j0 a_j+1,0 ...]
     double amax[LBMPC_MAX_NX], bmax;  // max_j |S_A[j,k]|, max_j |S_b[j]|: rounding margin of the filter
@@ -145,6 +148,57 @@ __device__ __forceinline__ int uq_update(const CtxDev* __restrict__ C, double& a
     }
     if (changed) *changed = outside;
     return st;
+}
+
+// The same for a general-polytope prior (CtxDev::genW; rows in the caller's order): b_hat = alpha W_b + (1-alpha) W_A v,
+// m = max(b_hat, W_A w_new), homothety LP by vertex enumeration when w_new is outside (homothety_gen.hpp; oracle:
+// step_one with orc_homothety_general).  Kept out of line and fed by value so that the box kernels' register
+// allocation does not see it; bh_out (nW values in global memory, or null) receives b_hat of the returned set.
+struct UqRes { double alpha, v[LBMPC_MAX_NX]; int st, changed; };
+__device__ __noinline__ __attribute__((cold)) UqRes genw_uq_update(const CtxDev* __restrict__ C, int uq, double alpha, double v0, double v1, double v2,
+                                             double v3, double w0, double w1, double w2, double w3, double* bh_out) {
+    const int nW = C->gw.nW, nx = C->gw.nx;
+    double v[LBMPC_MAX_NX] = {v0, v1, v2, v3}, w[LBMPC_MAX_NX] = {w0, w1, w2, w3}, bh[LBMPC_MAX_NW], mm[LBMPC_MAX_NW];
+    bool outside = false;
+    int st = 0;
+    for (int j = 0; j < nW; ++j) {
+        double t = 0.0;
+        for (int k = 0; k < nx; ++k) t = fma(C->gw.WA[j * nx + k], v[k], t);
+        bh[j] = alpha * C->gw.Wb[j] + (1.0 - alpha) * t;
+    }
+    if (uq) {
+        for (int j = 0; j < nW; ++j) {
+            double hw = 0.0;
+            for (int k = 0; k < nx; ++k) hw = fma(C->gw.WA[j * nx + k], w[k], hw);
+            mm[j] = bh[j];
+            if (hw > bh[j]) { mm[j] = hw; outside = true; }
+        }
+        if (outside) {
+            uint32_t mask;
+            st = homothety_general_dev(C->gw, mm, alpha, v, mask);
+            for (int j = 0; j < nW; ++j) {
+                double t = 0.0;
+                for (int k = 0; k < nx; ++k) t = fma(C->gw.WA[j * nx + k], v[k], t);
+                bh[j] = alpha * C->gw.Wb[j] + (1.0 - alpha) * t;
+            }
+        }
+    }
+    if (bh_out) for (int j = 0; j < nW; ++j) bh_out[j] = bh[j];
+    UqRes r;
+    r.alpha = alpha; r.st = st; r.changed = outside ? 1 : 0;
+    for (int k = 0; k < LBMPC_MAX_NX; ++k) r.v[k] = k < nx ? v[k] : 0.0;
+    return r;
+}
+// initial set of a closed-loop trial from the row maxima of its information set (InitialSetComputation.m:48-59)
+__device__ __noinline__ __attribute__((cold)) UqRes genw_initial(const CtxDev* __restrict__ C, const double* __restrict__ m0) {
+    double m[LBMPC_MAX_NW], v[LBMPC_MAX_NX];
+    for (int j = 0; j < C->gw.nW; ++j) m[j] = m0[j];
+    UqRes r;
+    uint32_t mask;
+    r.st = homothety_general_dev(C->gw, m, r.alpha, v, mask);
+    r.changed = 1;
+    for (int k = 0; k < LBMPC_MAX_NX; ++k) r.v[k] = k < C->gw.nx ? v[k] : 0.0;
+    return r;
 }
 
 // q = (1-alpha) T v - x ; returns min_r (1 - h_k[r]) and its first index (h_k closed form :80-84)

@@ -524,6 +524,8 @@ typedef struct orc_ctx {
     double Wb[LBMPC_MAX_NW];
     int pr[LBMPC_MAX_NX], qr[LBMPC_MAX_NX];
     double ic[LBMPC_MAX_NW];
+    int isbox;                      /* 0: W is a general polytope, the set update is orc_homothety_general */
+    double WAcm[LBMPC_MAX_NW * LBMPC_MAX_NX]; /* W_A column-major (the LP routines take the caller's layout) */
     int hasE;                       /* orc_set_certificate: benchmark variant only (see step_one) */
     double ME[LBMPC_MAX_NX * LBMPC_MAX_NX];
 } orc_ctx;
@@ -608,7 +610,11 @@ int orc_uqmpc_create(const lbmpc_params* p, orc_ctx** out) {
     }
     free(M); free(M2);
     for (int j = 0; j < c->nW; ++j) { for (int k = 0; k < nx; ++k) c->WA[j * nx + k] = CM(p->W_A, c->nW, j, k); c->Wb[j] = p->W_b[j]; }
+    memcpy(c->WAcm, p->W_A, sizeof(double) * (size_t)c->nW * nx);
     int rc = orc_box_structure(p->W_A, c->nW, nx, c->pr, c->qr, c->ic);
+    c->isbox = rc == 0;
+    /* UQRobustMPC.m:124-139 takes any polytope W: vertex enumeration then (nx + 1 <= nW) */
+    if (rc == LBMPC_ERR_UNSUPPORTED && c->nW >= nx + 1) rc = 0;
     if (rc) { free(c->SA); free(c->Sb); free(c->H); free(c); return rc; }
     *out = c;
     return 0;
@@ -854,7 +860,8 @@ static int step_one(const orc_ctx* c, int uq_update, const double* x, double alp
             if (hw > bh[j]) { mm[j] = hw; outside = 1; }
         }
         if (outside) {
-            int st = orc_homothety_box(c->pr, c->qr, c->ic, c->Wb, nx, mm, &alpha, v, NULL);
+            int st = c->isbox ? orc_homothety_box(c->pr, c->qr, c->ic, c->Wb, nx, mm, &alpha, v, NULL)
+                              : orc_homothety_general(c->WAcm, c->Wb, nW, nx, mm, &alpha, v, NULL);
             if (st > status) status = st;
             for (int j = 0; j < nW; ++j) {
                 double t = 0.0;
@@ -956,7 +963,8 @@ static void mc_trial(const orc_ctx* c, const lbmpc_sampler* smp, const lbmpc_mc_
                 if (acc > m[j]) m[j] = acc;
             }
         }
-        int st = orc_homothety_box(c->pr, c->qr, c->ic, c->Wb, nx, m, &alpha, v, NULL);
+        int st = c->isbox ? orc_homothety_box(c->pr, c->qr, c->ic, c->Wb, nx, m, &alpha, v, NULL)
+                          : orc_homothety_general(c->WAcm, c->Wb, nW, nx, m, &alpha, v, NULL);
         if (st > status) status = st;
         if (out->alpha0) out->alpha0[t] = alpha;
         double x[LBMPC_MAX_NX], xprev[LBMPC_MAX_NX], uprev[LBMPC_MAX_NZ];
