@@ -54,6 +54,41 @@ struct DevBuf {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (LB_WAVE - 1); }
 
+// Issue priority of the two waves that share a SIMD in an 8-wave block (waves w and w + 4).  The arbiter serves the
+// older wave first, so the younger one of every pair falls behind and then runs alone, at the single-wave issue rate;
+// and the kernel ends with its slowest wave.  prio_tick() is called at every closed-loop step and solver trip:
+// LBMPC_PRIO_MODE 1: the two take turns, periods of 2^SHIFT shader clocks; 3: the wave that is behind (lower step
+// index, published in LDS: lb_prog) goes first, turns as in mode 1 while they are level; 0: hardware order.
+#ifndef LBMPC_PRIO_MODE
+#define LBMPC_PRIO_MODE 3
+#endif
+#ifndef LBMPC_PRIO_SHIFT
+#define LBMPC_PRIO_SHIFT 18    // nx <= 3
+#endif
+#ifndef LBMPC_PRIO_SHIFT4
+#define LBMPC_PRIO_SHIFT4 20   // nx = 4
+#endif
+#if LBMPC_PRIO_MODE == 3
+__shared__ int lb_prog[8];   // step index of each wave of an 8-wave block (static LDS: 32 B on top of the dynamic allocation)
+#endif
+template <int SHIFT>
+__device__ __forceinline__ void prio_tick(int mine /* step index; < 0: the one published last */) {
+#if LBMPC_PRIO_MODE != 0
+    if (blockDim.x != 512) return;   // one wave per SIMD: nothing to arbitrate
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned t = (unsigned)(__builtin_readcyclecounter() >> SHIFT);
+    bool hi = ((t ^ (unsigned)(wave >> 2)) & 1u) != 0;
+#if LBMPC_PRIO_MODE == 3
+    volatile int* vp = lb_prog;
+    if (mine >= 0) { if ((threadIdx.x & 63) == 0) vp[wave] = mine; } else mine = vp[wave];
+    mine = __builtin_amdgcn_readfirstlane(mine);
+    const int other = __builtin_amdgcn_readfirstlane(vp[wave ^ 4]);
+    hi = mine < other || (mine == other && hi);
+#endif
+    if (hi) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
 // Orders LDS traffic of one wave: LDS ops of a wave execute in issue order, so a compiler-level
 // fence plus a wave barrier is enough to hand data between lanes of the same wave through LDS.
 __device__ __forceinline__ void wave_sync() {

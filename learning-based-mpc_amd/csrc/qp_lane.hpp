@@ -132,6 +132,7 @@ __device__ __forceinline__ void lane_qp_solve(const CtxDev* __restrict__ C, cons
     bool pending = false;   // this lane waits for a full scan (its z does not move meanwhile)
     while (__builtin_amdgcn_ballot_w64(!done) != 0) {
         ctr[0] += 1;
+        prio_tick<(NX == 4 ? LBMPC_PRIO_SHIFT4 : LBMPC_PRIO_SHIFT)>(-1);
 #ifdef LBMPC_PROFILE
         const long long pt0 = clock64();
         long long pscan = 0;

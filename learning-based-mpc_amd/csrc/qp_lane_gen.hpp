@@ -25,7 +25,9 @@
 
 namespace lbmpc {
 
+#ifndef LG_NQL
 #define LG_NQL 8                                   // active rows a lane can hold (C1: <= 8, C3: <= 4 observed)
+#endif
 #define LG_LP (LG_NQL * (LG_NQL + 1) / 2)          // packed factor
 #define LG_SLOTS (LG_LP + LBMPC_MAX_NC)            // + (1 - h_k)[r]
 __host__ __device__ inline int lanegen_doubles(int lanes) { return LG_SLOTS * lanes; }
@@ -280,6 +282,7 @@ __device__ __forceinline__ void lanegen_qp_solve(const CtxDev* __restrict__ C, c
 
     while (__builtin_amdgcn_ballot_w64(!done) != 0) {
         ctr[0] += 1;
+        prio_tick<(NX == 4 ? LBMPC_PRIO_SHIFT4 : LBMPC_PRIO_SHIFT)>(-1);
         LGP_T(t_a);
         // ---- Step 1: a violated row at the current z for the lanes without a pivot ----
         const bool s1 = !done && !have_p && !pending;

@@ -538,15 +538,24 @@ extern "C" int lbmpc_sample_information_sets_dev(const lbmpc_sampler* smp, const
 }
 
 namespace lbmpc {
-// lanes per information set: the smallest power of two >= N, at most a wave (small sets share a wave)
-static int lanes_per_set(int64_t N) {
-    int lps = 4;
-    while (lps < LB_WAVE && lps < N) lps <<= 1;
-    return lps;
+// lanes per information set (a power of two; results do not depend on it: maxima are order-free, samples are keyed by
+// (set, index)).  A lane walks its samples independently of the others, so the more samples a lane has the closer the
+// wave's trip count (the slowest lane's) is to the mean and the fewer lanes idle in the remainder round: take as few
+// lanes per set as still leave LBMPC_SS_WAVES (8 per SIMD) waves in the launch, at most the smallest power of two >= N.
+// LBMPC_SS_LPS forces a value (diagnostic).
+static int lanes_per_set(int64_t N, int64_t batch) {
+    int by_n = 4;
+    while (by_n < LB_WAVE && by_n < N) by_n <<= 1;
+    static const int forced = [] { const char* e = getenv("LBMPC_SS_LPS"); return e ? atoi(e) : 0; }();
+    if (forced >= 4 && forced <= LB_WAVE && (forced & (forced - 1)) == 0) return forced < by_n ? forced : by_n;
+    const int64_t target_waves = 8192;
+    int by_occ = 4;
+    while (by_occ < LB_WAVE && batch * by_occ < target_waves * LB_WAVE) by_occ <<= 1;
+    return by_occ < by_n ? by_occ : by_n;
 }
 int launch_sample_sets(int nx, int nu, const SmpPhases* d, int nW, int64_t N, int64_t batch, uint64_t seed, uint64_t set0,
                        int max_attempts, double* samples_out_dev, double* m_out_dev, int* status_out_dev, hipStream_t st) {
-    const int lps = lanes_per_set(N);
+    const int lps = lanes_per_set(N, batch);
     const int64_t waves = (batch + (LB_WAVE / lps) - 1) / (LB_WAVE / lps);
     dim3 grid((unsigned)((waves + 3) / 4));
 #define LAUNCH_SS(NXV, NTV)                                                                                                      \

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void uqmpc_step_kernel(const CtxDev* __restric
 
 #ifdef LBMPC_PROFILE
 __device__ unsigned long long lbmpc_prof[48];
-__device__ unsigned long long lbmpc_prof_wave[3 * 4096];  // per wave: lifetime, solve ticks, rounds
+__device__ unsigned long long lbmpc_prof_wave[64 * 4096];  // per wave: [0..47] its phase counters (prof[6] lifetime incl. the final barrier, prof[37] before it), [48..63] work counters ctr[0..15]
 #define PROF_T(var) const long long var = clock64()
 #define PROF_ADD(slot, t0, t1) prof[slot] += (t1) - (t0)
 #define PROF_PTR (prof + 8)
@@ -333,6 +333,9 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, M
     double* lgs = ws_base + nwaves * ws_doubles(nz) + wave * lanegen_doubles(a.gen_lanes);
     int* hist = reinterpret_cast<int*>(ws_base + nwaves * (ws_doubles(nz) + lanegen_doubles(a.gen_lanes)));   // MC_HIST_INTS
     for (int i = threadIdx.x; i < MC_HIST_INTS; i += blockDim.x) hist[i] = 0;
+#if LBMPC_PRIO_MODE == 3
+    if (threadIdx.x < 8) lb_prog[threadIdx.x] = 0;
+#endif
     __syncthreads();
     unsigned ctr[MC_NCTR];  // wave-uniform work counters (lbmpc_mc_counters)
 #pragma unroll
@@ -406,7 +409,12 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, M
         }
 #pragma unroll
         for (int t = 0; t < T; ++t) live[t] = valid[t] && !a.resume;
+#ifdef LBMPC_PROFILE
+        long long p_last = clock64();
+        prof[35] += p_last - pk0;   // prologue (first chunk of the wave)
+#endif
         for (int k = a.kseg0; k < a.kseg1; ++k) {
+            prio_tick<(NX == 4 ? LBMPC_PRIO_SHIFT4 : LBMPC_PRIO_SHIFT)>(k);
             if (a.resume) {
 #pragma unroll
                 for (int t = 0; t < T; ++t)
@@ -433,6 +441,9 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, M
             int aomh[T];
             bool need[T];
             PROF_T(p0);
+#ifdef LBMPC_PROFILE
+            prof[36] += p0 - p_last;   // between the steps: loop back, resume test, xi loads issued
+#endif
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 // LVModeling first (Case_3...:58; ModelingCar.m:42-43): xi_LV, xi_EV come from the pre-pass
@@ -608,6 +619,9 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, M
                 }
                 PROF_T(p5);
                 PROF_ADD(3, p4, p5);
+#ifdef LBMPC_PROFILE
+                p_last = p5;
+#endif
             }
         }
 #pragma unroll
@@ -636,6 +650,10 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, M
     }
     if (lane == 0 && a.counters)
         for (int i = 0; i < MC_NCTR; ++i) if (ctr[i]) atomicAdd(a.counters + i, (unsigned long long)ctr[i]);
+#ifdef LBMPC_PROFILE
+    PROF_T(pkb);
+    prof[37] = pkb - pk0;
+#endif
     __syncthreads();
     if (a.counters)
         for (int i = threadIdx.x; i < MC_HIST_INTS; i += blockDim.x) if (hist[i]) atomicAdd(a.counters + 32 + i, (unsigned long long)hist[i]);
@@ -646,13 +664,16 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, M
         for (int i = 0; i < 48; ++i) if (i != 7) atomicAdd(&lbmpc_prof[i], (unsigned long long)prof[i]);
         atomicMax(&lbmpc_prof[7], (unsigned long long)prof[6]);  // slowest wave
         const int gw = blockIdx.x * nwaves + wave;
-        if (gw < 4096) { lbmpc_prof_wave[3 * gw] = prof[6]; lbmpc_prof_wave[3 * gw + 1] = prof[2]; lbmpc_prof_wave[3 * gw + 2] = prof[5]; }
+        if (gw < 4096) {
+            for (int i = 0; i < 48; ++i) lbmpc_prof_wave[64 * gw + i] = prof[i];
+            for (int i = 0; i < 16; ++i) lbmpc_prof_wave[64 * gw + 48 + i] = i < MC_NCTR ? ctr[i] : 0;
+        }
     }
 #endif
 }
 #ifdef LBMPC_PROFILE
 extern "C" int lbmpc_prof_read_waves(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(lbmpc_prof_wave), sizeof(unsigned long long) * 3 * 4096) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(lbmpc_prof_wave), sizeof(unsigned long long) * 64 * 4096) == hipSuccess ? 0 : -1;
 }
 extern "C" int lbmpc_prof_read(unsigned long long* out, int reset) {
     unsigned long long z[48] = {0};
@@ -902,8 +923,8 @@ static const size_t LDS_LIMIT = 160 * 1024;
 static int pick_waves(const lbmpc_ctx* c, int want) {
     const size_t wsb = (size_t)ws_doubles(c->h.nz) * 8;
     int w = want;
-    while (w > 1 && c->lds_const_bytes + (size_t)w * wsb + MC_HIST_INTS * 4 > LDS_LIMIT) w >>= 1;
-    if (c->lds_const_bytes + (size_t)w * wsb + MC_HIST_INTS * 4 > LDS_LIMIT) return 0;
+    while (w > 1 && c->lds_const_bytes + (size_t)w * wsb + (MC_HIST_INTS + MC_PROG_INTS) * 4 > LDS_LIMIT) w >>= 1;
+    if (c->lds_const_bytes + (size_t)w * wsb + (MC_HIST_INTS + MC_PROG_INTS) * 4 > LDS_LIMIT) return 0;
     return w;
 }
 // lanes of the per-wave LDS region of the general lane solver: the largest power of two <= min(lanes_per_wave, 32)
@@ -913,7 +934,7 @@ static int pick_gen_lanes(const lbmpc_ctx* c, int waves, int lanes_per_wave) {
     if (!c->h.gen_ok) return 0;
     int cap = 32;
     if (const char* e = getenv("LBMPC_GEN_LANES")) { const int v = atoi(e); if (v >= 0 && v <= 64) cap = v; }
-    const size_t base = c->lds_const_bytes + (size_t)waves * ws_doubles(c->h.nz) * 8 + MC_HIST_INTS * 4;
+    const size_t base = c->lds_const_bytes + (size_t)waves * ws_doubles(c->h.nz) * 8 + (MC_HIST_INTS + MC_PROG_INTS) * 4;
     int gl = 4;
     while (gl < lanes_per_wave && gl < 64) gl <<= 1;   // the smallest power of two that holds the wave's trials ...
     while (gl > cap) gl >>= 1;                          // ... up to the cap (more trials are served in groups)

@@ -96,6 +96,7 @@ __host__ __device__ inline int lds_const_doubles(const CtxDev& h) {
 __host__ __device__ inline int ws_doubles(int) { return 4 * 48; }  // GWS_PER_WAVE: four row slots per wave
 #define MC_NCTR 20        // work counters kept per wave in registers
 #define MC_STATS_N 160    // u64 slots of lbmpc_ctx::counters
+#define MC_PROG_INTS 8    // static LDS of prio_tick (lb_prog), counted against the LDS limit
 #define MC_HIST_INTS 128  // per-block LDS histograms (ints): iterations per QP solve [0, 64), final active-set size [64, 128)
 
 }  // namespace lbmpc

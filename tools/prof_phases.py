@@ -36,11 +36,11 @@ if g[4] > 0:
 print("  per wave-step ticks: Bu_lv %.0f  uq_update %.0f  tighten %.0f  first_pass %.0f  ev+dyn %.0f" % tuple(
     v[i] / (trials / 64 * K) for i in (16, 17, 18, 1, 3)))
 print("  wave lifetime: mean %.3e ticks, max %.3e ticks (kernel ends with the slowest wave)" % (v[6] / (trials / 64), v[7]))
-wb = (ctypes.c_ulonglong * (3 * 4096))()
+wb = (ctypes.c_ulonglong * (64 * 4096))()
 lib.lbmpc_prof_read_waves.argtypes = [ctypes.c_void_p]
 lib.lbmpc_prof_read_waves(wb)
-w = np.array(list(wb), dtype=np.float64).reshape(4096, 3)[: trials // 64]
-life, solve, rounds = w[:, 0], w[:, 1], w[:, 2]
+w = np.array(list(wb), dtype=np.float64).reshape(4096, 64)[: trials // 64]
+life, solve, rounds = w[:, 6], w[:, 2], w[:, 5]
 print("  lifetime quantiles (1e6 ticks) min/50/90/99/max:", np.round(np.quantile(life, [0, .5, .9, .99, 1]) / 1e6, 2))
 print("  solve ticks quantiles (1e6):", np.round(np.quantile(solve, [0, .5, .9, .99, 1]) / 1e6, 2), " rounds:", np.quantile(rounds, [0, .5, 1]))
 print("  corr(lifetime, rounds) %.2f  corr(lifetime, solve) %.2f" % (np.corrcoef(life, rounds)[0, 1], np.corrcoef(life, solve)[0, 1]))

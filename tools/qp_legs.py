@@ -15,7 +15,8 @@ import torch
 from lbmpc import core, dev, params
 
 LEGS = {"C1": ("2x2", [-12.0, 5.0], 65536, 50, 100, 1), "C3": ("3x3", None, 10000, 20, 10, 5),   # C3: x0 = Case_5 near-boundary state (api.case_5_start)
-        "C4t": ("4x4", [-12.0, 5.0, 0.0, 0.0], 131072, 32, 10, 4)}
+        "C4t": ("4x4", [-12.0, 5.0, 0.0, 0.0], 131072, 32, 10, 4),
+        "C4": ("4x4", [-12.0, 5.0, 0.0, 0.0], 131072, 1000, 10, 4)}   # the headline launch: pre-pass + transient + steady state
 
 
 def main():
