@@ -1,5 +1,5 @@
-export LBMPC_LIB=$PWD/learning-based-mpc_amd/csrc/dev_lbmpc.so
-for cfg in "8 8" "4 10" "5 8" "8 5" "4 16" "6 7" "4 12"; do
+export LBMPC_LIB=${LBMPC_LIB:-$PWD/learning-based-mpc_amd/csrc/liblbmpc_hip.so}
+for cfg in "4 10" "8 5" "8 6" "8 8" "8 10" "8 4"; do
   set -- $cfg
   LBMPC_MC_WAVES=$1 LBMPC_MC_TPW=$2 timeout -k 10 100 python -u tools/qp_legs.py C3 --reps 10 --check 2>&1 | python3 -c "
 import sys, json
