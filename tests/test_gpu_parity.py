@@ -146,6 +146,20 @@ def test_sampler_stream_bit_exact(core, P, smp):
         assert (np.einsum("rk,bkn->brn", H[:, :-1], S) <= H[:, -1][None, :, None] + 1e-9).all()
 
 
+def test_sampler_few_lanes_per_set(core, P, smp):
+    """large batches of small information sets (the closed loop's I0 pre-pass: one set per trial) take fewer lanes per set
+    than samples -- several sets per wave, several samples per lane, ragged last round; samples, maxima and statuses
+    == oracle (set_learning.hip lanes_per_set)"""
+    for N, batch, set0 in [(50, 20000, 3), (100, 70000, 0), (10, 140000, 5), (37, 9000, 11)]:
+        S, m, st = core.sample_information_sets(smp, P["W_A"], N, batch, seed=9, set0=set0)
+        n = 1500   # the oracle on the first and the last sets
+        for lo in (0, batch - n):
+            S2, m2, st2 = oracle_core.sample_information_sets(smp, P["W_A"], N, n, seed=9, set0=set0 + lo)
+            np.testing.assert_array_equal(S[lo:lo + n], S2)
+            np.testing.assert_array_equal(m[lo:lo + n], m2)
+            np.testing.assert_array_equal(st[lo:lo + n], st2)
+
+
 def test_case_2_statistics(core, P, smp):
     """Case_2: vol(W_hat_0) = alpha^nx vol(W) vs card(I_0^w); means agree with Results_2 statistically
     (reference RNG unseeded) and the GPU equals the oracle exactly."""
