@@ -1047,6 +1047,9 @@ extern "C" int lbmpc_uqmpc_step(lbmpc_ctx* c, int64_t batch, int uq_update, cons
     return 0;
 }
 
+#if defined(LBMPC_DEV_NX4) && !defined(LBMPC_DEV_NX4_GW)
+#define LBMPC_DEV_NX4_GW true   // diagnostic: false = the box-only instantiation for nx = 4
+#endif
 namespace lbmpc {
 // launch shape of the closed-loop kernels for a batch (shared by lbmpc_mc_run_dev and lbmpc_mc_plan)
 struct McPlan {
@@ -1114,7 +1117,7 @@ extern "C" int lbmpc_mc_plan(lbmpc_ctx* c, int64_t trials, int steps, int32_t* o
     if (int rc = mc_plan(c, trials, steps, &p)) return rc;
     int vg = 0, sc = 0, sl = 0, rc = 0;
 #ifdef LBMPC_DEV_NX4
-    rc = kern_attrs(mc_kernel<4, 1, true>, &vg, &sc, &sl);
+    rc = kern_attrs(mc_kernel<4, 1, LBMPC_DEV_NX4_GW>, &vg, &sc, &sl);
 #elif defined(LBMPC_DEV_FAST)
     switch (c->h.nx * 2 + (c->h.genW ? 1 : 0)) {
         case 4: rc = kern_attrs(mc_kernel<2, 1, false>, &vg, &sc, &sl); break;
@@ -1277,9 +1280,12 @@ extern "C" int lbmpc_mc_run_dev(lbmpc_ctx* c, const lbmpc_sampler* smp, const lb
 #define LAUNCH_MC1(NXV, BOXGW)                                                                  \
     do { if (c->h.genW || BOXGW) LAUNCH_MC_GW(NXV, 1, true); else LAUNCH_MC_GW(NXV, 1, false); } while (0)
 #ifdef LBMPC_DEV_NX4
+#ifndef LBMPC_DEV_NX4_GW
+#define LBMPC_DEV_NX4_GW true
+#endif
 #define LAUNCH_MC_ALL()                                                                         \
     switch (c->h.nx * 2 + (wide ? 1 : 0)) {                                                     \
-        case 8: LAUNCH_MC_GW(4, 1, true); break;                                                \
+        case 8: LAUNCH_MC_GW(4, 1, LBMPC_DEV_NX4_GW); break;                                    \
         default: set_error("development build: nx = 4, one trial per lane"); return LBMPC_ERR_UNSUPPORTED; \
     }
 #elif defined(LBMPC_DEV_FAST)
