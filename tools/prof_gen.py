@@ -11,7 +11,7 @@ if LEG == "C1":
 elif LEG == "C4t":   # build: make prof4
     P = params.load("4x4"); x0 = [-12.0, 5.0, 0.0, 0.0]; trials, K, card, seed = 131072, 32, 10, 4
 else:
-    P = params.load("3x3"); x0 = None; trials, K, card, seed = 10000, 20, 10, 5
+    P = params.load("3x3"); x0 = None; trials, K, card, seed = 10000, 20, 10, int(os.environ.get("SEED", 5))
 trials = int(os.environ.get("TRIALS", trials))
 core.init(0)
 if x0 is None:
