@@ -59,6 +59,9 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & (LB_WAVE - 1); }
 // and the kernel ends with its slowest wave.  prio_tick() is called at every closed-loop step and solver trip:
 // LBMPC_PRIO_MODE 1: the two take turns, periods of 2^SHIFT shader clocks; 3: the wave that is behind (lower step
 // index, published in LDS: lb_prog) goes first, turns as in mode 1 while they are level; 0: hardware order.
+#if defined(LBMPC_PROFILE) && !defined(LBMPC_PROFILE_LIGHT)
+#define LBMPC_PROFILE_FULL   // per-phase clocks inside the closed-loop kernels; LBMPC_PROFILE_LIGHT keeps only the per-wave lifetime
+#endif
 #ifndef LBMPC_PRIO_MODE
 #define LBMPC_PRIO_MODE 3
 #endif

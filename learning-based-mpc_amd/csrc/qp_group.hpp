@@ -345,7 +345,7 @@ __device__ __forceinline__ void group_qp_solve(const CtxDev* __restrict__ C, con
                                                int* hint_rows /* this row's 16 candidate slots in HBM, or null */,
                                                int* hint_n /* their count (in: previous step, out: this solve) */,
                                                long long* prof = nullptr) {
-#ifdef LBMPC_PROFILE
+#ifdef LBMPC_PROFILE_FULL
 #define GP_T(var) const long long var = clock64()
 #define GP_ADD(slot, t0, t1) prof[slot] += (t1) - (t0)
 #define GP_INC(slot) prof[slot] += 1

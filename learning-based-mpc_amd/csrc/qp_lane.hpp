@@ -133,7 +133,7 @@ __device__ __forceinline__ void lane_qp_solve(const CtxDev* __restrict__ C, cons
     while (__builtin_amdgcn_ballot_w64(!done) != 0) {
         ctr[0] += 1;
         prio_tick<(NX == 4 ? LBMPC_PRIO_SHIFT4 : LBMPC_PRIO_SHIFT)>(-1);
-#ifdef LBMPC_PROFILE
+#ifdef LBMPC_PROFILE_FULL
         const long long pt0 = clock64();
         long long pscan = 0;
         if (prof) prof[4] += 1;
@@ -199,11 +199,11 @@ __device__ __forceinline__ void lane_qp_solve(const CtxDev* __restrict__ C, cons
                     }
                     double fb[4];
                     int fj[4];
-#ifdef LBMPC_PROFILE
+#ifdef LBMPC_PROFILE_FULL
                     const long long ps0 = clock64();
 #endif
                     scan_S_lanes<NX>(C, L, src, alpha, e, fb, fj);
-#ifdef LBMPC_PROFILE
+#ifdef LBMPC_PROFILE_FULL
                     pscan += clock64() - ps0;
                     if (prof) prof[5] += 1;
 #endif
@@ -249,7 +249,7 @@ __device__ __forceinline__ void lane_qp_solve(const CtxDev* __restrict__ C, cons
                 }
             }
         }
-#ifdef LBMPC_PROFILE
+#ifdef LBMPC_PROFILE_FULL
         const long long pt1 = clock64();
         if (prof) { prof[0] += pscan; prof[2] += (pt1 - pt0) - pscan; }
 #endif
@@ -362,7 +362,7 @@ __device__ __forceinline__ void lane_qp_solve(const CtxDev* __restrict__ C, cons
                 nq -= 1;
             }
         }
-#ifdef LBMPC_PROFILE
+#ifdef LBMPC_PROFILE_FULL
         if (prof) prof[1] += clock64() - pt1;
 #endif
     }

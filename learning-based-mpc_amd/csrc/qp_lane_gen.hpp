@@ -234,7 +234,7 @@ __device__ __forceinline__ void lanegen_qp_solve(const CtxDev* __restrict__ C, c
                                                  int* hint_rows /* this lane's 16 slots or null */, int* hint_n, double* z,
                                                  int& status, int& iters, int& nact, int* act /* LG_NQL */, bool& fallback,
                                                  unsigned* ctr, long long* prof = nullptr /* LBMPC_PROFILE: 10 phase slots */) {
-#ifdef LBMPC_PROFILE
+#ifdef LBMPC_PROFILE_FULL
 #define LGP_T(var) const long long var = clock64()
 #define LGP_ADD(slot, t0, t1) do { if (prof) prof[slot] += (t1) - (t0); } while (0)
 #else

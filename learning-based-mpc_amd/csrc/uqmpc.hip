@@ -127,7 +127,7 @@ __device__ __forceinline__ void solve_lanes(const CtxDev* __restrict__ C, const 
                                             long long* prof = nullptr) {
     ctr[0] += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(need));
     bool fb = need;
-#ifdef LBMPC_PROFILE
+#ifdef LBMPC_PROFILE_FULL
     const long long tp0 = clock64();
 #endif
     if (C->lane_solver) {
@@ -157,7 +157,7 @@ __device__ __forceinline__ void solve_lanes(const CtxDev* __restrict__ C, const 
         }
         fb = need && fb;
     }
-#ifdef LBMPC_PROFILE
+#ifdef LBMPC_PROFILE_FULL
     const long long tp1 = clock64();
     if (prof) prof[24] += tp1 - tp0;
 #endif
@@ -201,14 +201,14 @@ __device__ __forceinline__ void solve_lanes(const CtxDev* __restrict__ C, const 
             }
         }
     }
-#ifdef LBMPC_PROFILE
+#ifdef LBMPC_PROFILE_FULL
     const long long tp2 = clock64();
     if (prof) prof[25] += tp2 - tp1;
 #endif
     if (__builtin_amdgcn_ballot_w64(fb) != 0)
         solve_flagged<NX>(C, L, wws, fb, alpha, v, q, s0, c0, status, iters, nact_out, act_out, c_full, ctr, hint_base,
                           nhint_base, cl, prof);
-#ifdef LBMPC_PROFILE
+#ifdef LBMPC_PROFILE_FULL
     if (prof) prof[26] += clock64() - tp2;
 #endif
 }
@@ -309,9 +309,15 @@ __global__ __launch_bounds__(256) void uqmpc_step_kernel(const CtxDev* __restric
 #ifdef LBMPC_PROFILE
 __device__ unsigned long long lbmpc_prof[48];
 __device__ unsigned long long lbmpc_prof_wave[64 * 4096];  // per wave: [0..47] its phase counters (prof[6] lifetime incl. the final barrier, prof[37] before it), [48..63] work counters ctr[0..15]
+#ifdef LBMPC_PROFILE_FULL
 #define PROF_T(var) const long long var = clock64()
 #define PROF_ADD(slot, t0, t1) prof[slot] += (t1) - (t0)
 #define PROF_PTR (prof + 8)
+#else   // LBMPC_PROFILE_LIGHT: only the wave's lifetime and its work counters are recorded (two clock reads per wave)
+#define PROF_T(var) const long long var = 0
+#define PROF_ADD(slot, t0, t1)
+#define PROF_PTR nullptr
+#endif
 #else
 #define PROF_PTR nullptr
 #define PROF_T(var)
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, M
 #ifdef LBMPC_PROFILE
     long long prof[48];
     for (int i = 0; i < 48; ++i) prof[i] = 0;
-    PROF_T(pk0);
+    const long long pk0 = clock64();
 #endif
     // a.tpw trials per wave and per t (64 for large batches; fewer lanes per wave for small ones, so that the solver
     // rounds of a step -- 4 QPs at a time -- spread over more waves)
@@ -409,7 +415,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, M
         }
 #pragma unroll
         for (int t = 0; t < T; ++t) live[t] = valid[t] && !a.resume;
-#ifdef LBMPC_PROFILE
+#ifdef LBMPC_PROFILE_FULL
         long long p_last = clock64();
         prof[35] += p_last - pk0;   // prologue (first chunk of the wave)
 #endif
@@ -441,7 +447,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, M
             int aomh[T];
             bool need[T];
             PROF_T(p0);
-#ifdef LBMPC_PROFILE
+#ifdef LBMPC_PROFILE_FULL
             prof[36] += p0 - p_last;   // between the steps: loop back, resume test, xi loads issued
 #endif
 #pragma unroll
@@ -535,7 +541,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, M
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
                     const bool nd = live[t] && need[t];
-#ifdef LBMPC_PROFILE
+#ifdef LBMPC_PROFILE_FULL
                     prof[4] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(nd));
                     prof[5] += (__builtin_popcountll(__builtin_amdgcn_ballot_w64(nd)) + 3) >> 2;
 #endif
@@ -619,7 +625,7 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, M
                 }
                 PROF_T(p5);
                 PROF_ADD(3, p4, p5);
-#ifdef LBMPC_PROFILE
+#ifdef LBMPC_PROFILE_FULL
                 p_last = p5;
 #endif
             }
@@ -651,14 +657,14 @@ __global__ __launch_bounds__(512) void mc_kernel(const CtxDev* __restrict__ C, M
     if (lane == 0 && a.counters)
         for (int i = 0; i < MC_NCTR; ++i) if (ctr[i]) atomicAdd(a.counters + i, (unsigned long long)ctr[i]);
 #ifdef LBMPC_PROFILE
-    PROF_T(pkb);
+    const long long pkb = clock64();
     prof[37] = pkb - pk0;
 #endif
     __syncthreads();
     if (a.counters)
         for (int i = threadIdx.x; i < MC_HIST_INTS; i += blockDim.x) if (hist[i]) atomicAdd(a.counters + 32 + i, (unsigned long long)hist[i]);
 #ifdef LBMPC_PROFILE
-    PROF_T(pk1);
+    const long long pk1 = clock64();
     prof[6] = pk1 - pk0;
     if (lane == 0) {
         for (int i = 0; i < 48; ++i) if (i != 7) atomicAdd(&lbmpc_prof[i], (unsigned long long)prof[i]);
